@@ -1,0 +1,265 @@
+"""ctypes binding of oracle/librem2d_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see oracle/rem2d_oracle.h).  The product package gym_rem2d_amd
+never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librem2d_oracle.so")
+
+FLAG_CONTINUOUS = 1
+FLAG_SLEEP_RESET_ALWAYS = 2
+FLAG_NO_SLEEP = 4
+
+MORPH_F32 = ("hx", "hy", "x", "y", "angle", "ax", "ay", "bx", "by", "torque", "lower", "upper")
+MORPH_F64 = ("amp", "phase", "freq", "offset", "istate")
+
+
+class OMorph(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("lanes", C.c_int32), ("shape", C.c_void_p),
+                ("hx", C.c_void_p), ("hy", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("angle", C.c_void_p), ("parent", C.c_void_p),
+                ("ax", C.c_void_p), ("ay", C.c_void_p), ("bx", C.c_void_p), ("by", C.c_void_p),
+                ("torque", C.c_void_p), ("lower", C.c_void_p), ("upper", C.c_void_p),
+                ("amp", C.c_void_p), ("phase", C.c_void_p), ("freq", C.c_void_p),
+                ("offset", C.c_void_p), ("istate", C.c_void_p)]
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "rem2d_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librem2d_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.rem2d_oracle_terrain_create.restype = C.c_void_p
+        L.rem2d_oracle_terrain_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float]
+        L.rem2d_oracle_terrain_destroy.argtypes = [C.c_void_p]
+        L.rem2d_oracle_world_create.restype = C.c_void_p
+        L.rem2d_oracle_world_create.argtypes = [C.c_void_p, C.c_uint]
+        L.rem2d_oracle_world_destroy.argtypes = [C.c_void_p]
+        L.rem2d_oracle_add_box.argtypes = [C.c_void_p] + [C.c_float] * 5
+        L.rem2d_oracle_add_circle.argtypes = [C.c_void_p] + [C.c_float] * 4
+        L.rem2d_oracle_add_joint.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 7
+        L.rem2d_oracle_set_controller.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5
+        L.rem2d_oracle_set_motor_speed.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.rem2d_oracle_set_velocity.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 3
+        L.rem2d_oracle_set_gravity.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.rem2d_oracle_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
+        L.rem2d_oracle_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("num_bodies", "num_joints", "position_iterations", "toi_events"):
+            getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p]
+        for f in ("get_bodies", "get_mass", "get_joints"):
+            getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_get_island_joint_order.argtypes = [C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_get_contacts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_get_manifold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.rem2d_oracle_get_fat_aabb.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rem2d_oracle_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_sin.restype = C.c_double
+        L.rem2d_oracle_sin.argtypes = [C.c_double]
+        L.rem2d_oracle_box_mass.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_circle_mass.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 5
+        L.rem2d_oracle_world_from_morph.restype = C.c_void_p
+        L.rem2d_oracle_world_from_morph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Terrain:
+    """Static terrain: npts heights -> npts-1 edge bodies (+ hardcore boxes)."""
+
+    def __init__(self, xs, ys, polys=None, friction=2.5):
+        self.xs = np.ascontiguousarray(xs, dtype=np.float32)
+        self.ys = np.ascontiguousarray(ys, dtype=np.float32)
+        self.polys = np.ascontiguousarray(polys if polys is not None else np.zeros((0, 4, 2)), dtype=np.float32)
+        self.h = lib().rem2d_oracle_terrain_create(_ptr(self.xs), _ptr(self.ys), len(self.xs),
+                                                   _ptr(self.polys), len(self.polys), friction)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().rem2d_oracle_terrain_destroy(self.h)
+            self.h = None
+
+
+def make_omorph(m):
+    """m: dict of numpy arrays in [env][lane] layout (see gym_rem2d_amd.compiler.Morphology.arrays)."""
+    keep = {}
+    om = OMorph()
+    om.n_envs = int(m["n_envs"])
+    om.lanes = int(m["lanes"])
+    for k in ("shape", "parent"):
+        keep[k] = np.ascontiguousarray(m[k], dtype=np.int32)
+        setattr(om, k, keep[k].ctypes.data)
+    for k in MORPH_F32:
+        keep[k] = np.ascontiguousarray(m[k], dtype=np.float32)
+        setattr(om, k, keep[k].ctypes.data)
+    for k in MORPH_F64:
+        keep[k] = np.ascontiguousarray(m[k], dtype=np.float64)
+        setattr(om, k, keep[k].ctypes.data)
+    return om, keep
+
+
+class World:
+    def __init__(self, terrain, flags=0, handle=None):
+        self.terrain = terrain
+        self.h = handle if handle is not None else lib().rem2d_oracle_world_create(terrain.h, flags)
+
+    @classmethod
+    def from_morph(cls, terrain, m, env, flags=0):
+        om, keep = make_omorph(m)
+        h = lib().rem2d_oracle_world_from_morph(terrain.h, C.byref(om), env, flags)
+        return cls(terrain, flags, handle=h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().rem2d_oracle_world_destroy(self.h)
+            self.h = None
+
+    def add_box(self, hx, hy, x, y, angle=0.0):
+        return lib().rem2d_oracle_add_box(self.h, hx, hy, x, y, angle)
+
+    def add_circle(self, r, x, y, angle=0.0):
+        return lib().rem2d_oracle_add_circle(self.h, r, x, y, angle)
+
+    def add_joint(self, a, b, ax, ay, bx, by, torque=50.0, lower=-np.pi / 2, upper=np.pi / 2):
+        return lib().rem2d_oracle_add_joint(self.h, a, b, ax, ay, bx, by, torque, lower, upper)
+
+    def set_controller(self, joint, amp, phase, freq, offset, istate=0.0):
+        lib().rem2d_oracle_set_controller(self.h, joint, amp, phase, freq, offset, istate)
+
+    def set_motor_speed(self, joint, speed):
+        lib().rem2d_oracle_set_motor_speed(self.h, joint, speed)
+
+    def set_velocity(self, body, vx, vy, w):
+        lib().rem2d_oracle_set_velocity(self.h, body, vx, vy, w)
+
+    def set_gravity(self, gx, gy):
+        lib().rem2d_oracle_set_gravity(self.h, gx, gy)
+
+    def step(self, dt=1.0 / 50, vel_iters=180, pos_iters=60):
+        lib().rem2d_oracle_world_step(self.h, dt, vel_iters, pos_iters)
+
+    def env_step(self):
+        r = C.c_double()
+        d = C.c_int()
+        lib().rem2d_oracle_env_step(self.h, C.byref(r), C.byref(d))
+        return r.value, d.value
+
+    @property
+    def n_bodies(self):
+        return lib().rem2d_oracle_num_bodies(self.h)
+
+    @property
+    def n_joints(self):
+        return lib().rem2d_oracle_num_joints(self.h)
+
+    def bodies(self):
+        out = np.zeros((self.n_bodies, 8), dtype=np.float32)
+        lib().rem2d_oracle_get_bodies(self.h, _ptr(out))
+        return out
+
+    def mass(self):
+        out = np.zeros((self.n_bodies, 4), dtype=np.float32)
+        lib().rem2d_oracle_get_mass(self.h, _ptr(out))
+        return out
+
+    def joints(self):
+        out = np.zeros((self.n_joints, 6), dtype=np.float32)
+        lib().rem2d_oracle_get_joints(self.h, _ptr(out))
+        return out
+
+    def island_joint_order(self):
+        out = np.zeros(64, dtype=np.int32)
+        n = lib().rem2d_oracle_get_island_joint_order(self.h, _ptr(out))
+        return out[:n].copy()
+
+    def contacts(self, body):
+        out = np.zeros((16, 8), dtype=np.int32)
+        fout = np.zeros((16, 4), dtype=np.float32)
+        n = lib().rem2d_oracle_get_contacts(self.h, body, _ptr(out), _ptr(fout))
+        return out[:n].copy(), fout[:n].copy()
+
+    def manifold(self, body, k):
+        out = np.zeros(8, dtype=np.float32)
+        lib().rem2d_oracle_get_manifold(self.h, body, k, _ptr(out))
+        return out
+
+    def fat_aabb(self, body):
+        out = np.zeros(4, dtype=np.float32)
+        lib().rem2d_oracle_get_fat_aabb(self.h, body, _ptr(out))
+        return out
+
+    @property
+    def position_iterations(self):
+        return lib().rem2d_oracle_position_iterations(self.h)
+
+    @property
+    def toi_events(self):
+        return lib().rem2d_oracle_toi_events(self.h)
+
+
+def sincosf(a):
+    s = C.c_float()
+    c = C.c_float()
+    lib().rem2d_oracle_sincosf(a, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sin64(x):
+    return lib().rem2d_oracle_sin(x)
+
+
+def box_mass(hx, hy):
+    m = C.c_float()
+    i = C.c_float()
+    lib().rem2d_oracle_box_mass(hx, hy, C.byref(m), C.byref(i))
+    return m.value, i.value
+
+
+def circle_mass(r):
+    m = C.c_float()
+    i = C.c_float()
+    lib().rem2d_oracle_circle_mass(r, C.byref(m), C.byref(i))
+    return m.value, i.value
+
+
+def batch_run(terrain, m, n_steps, n_threads=1, flags=0, trace=False):
+    """Run Modular2D.step n_steps times for every env of morphology dict m.
+
+    Returns dict(bodies [N,K,8], reward [N], done [N], fitness [N], trace [T,N,K,3] or None)."""
+    om, keep = make_omorph(m)
+    N, K = om.n_envs, om.lanes
+    bodies = np.zeros((N, K, 8), dtype=np.float32)
+    reward = np.zeros(N, dtype=np.float64)
+    done = np.zeros(N, dtype=np.int32)
+    fitness = np.zeros(N, dtype=np.float64)
+    tr = np.zeros((n_steps, N, K, 3), dtype=np.float32) if trace else None
+    rc = lib().rem2d_oracle_batch_run(terrain.h, C.byref(om), n_steps, n_threads, flags, _ptr(bodies),
+                                      _ptr(reward), _ptr(done), _ptr(fitness),
+                                      _ptr(tr) if trace else None)
+    if rc != 0:
+        raise RuntimeError("rem2d_oracle_batch_run failed: %d" % rc)
+    return dict(bodies=bodies, reward=reward, done=done, fitness=fitness, trace=tr)
