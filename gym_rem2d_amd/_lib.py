@@ -1,0 +1,104 @@
+"""ctypes binding of the C ABI in include/rem2d.h (librem2d.so, HIP/gfx950).
+
+The product path has no CPU fallback: if the library is missing this raises, loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "librem2d.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "rem2d.hip")
+
+FLAG_CONTINUOUS = 1
+FLAG_SLEEP_RESET_ALWAYS = 2
+FLAG_NO_SLEEP = 4
+
+CONTACT_SLOTS = 8
+SOLVER_SLOTS = 6
+ERR_PAIR_OVERFLOW = 1
+ERR_SOLVER_OVERFLOW = 2
+
+# field ids: order of the enum in include/rem2d.h
+FIELDS = [
+    "px", "py", "ang", "vx", "vy", "w", "sleept", "hx", "hy", "invm", "invi",
+    "fatlx", "fatly", "fatux", "fatuy",
+    "jax", "jay", "jbx", "jby", "jtorque", "jlower", "jupper",
+    "jimpx", "jimpy", "jimpz", "jmotorimp", "jmotorspeed",
+    "shape", "parent", "jround", "awake", "jlimit", "ccount",
+    "camp", "cphase", "cfreq", "coffset", "cistate",
+    "cedge", "cinfo", "ckey0", "ckey1", "cn0", "cn1", "ct0", "ct1",
+    "wod", "fitness", "reward", "done", "everdone", "frozen", "steps", "invdt0",
+    "newfix", "err", "positers", "toievents",
+]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+
+MORPH_FIELDS = ("shape", "hx", "hy", "x", "y", "angle", "parent", "jround", "ax", "ay", "bx", "by", "torque",
+                "lower", "upper", "amp", "phase", "freq", "offset", "istate")
+
+
+class WorldCfg(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("lanes", C.c_int32), ("flags", C.c_uint32), ("device", C.c_int32)]
+
+
+class Morph(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in MORPH_FIELDS]
+
+
+class Rem2dError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so (hipcc cross-compiles
+    without a GPU).  -ffp-contract=off keeps every binary32 operation separately rounded."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(_ROOT, "include", "rem2d.h"))):
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(_ROOT, "include"), SRC_PATH, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Rem2dError(
+            "gym_rem2d_amd: %s is missing -- the HIP extension is required (there is no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.rem2d_abi_version.restype = C.c_int
+    L.rem2d_last_error.restype = C.c_char_p
+    L.rem2d_state_bytes.restype = C.c_size_t
+    L.rem2d_state_bytes.argtypes = [C.POINTER(WorldCfg)]
+    L.rem2d_padded_envs.restype = C.c_int32
+    L.rem2d_padded_envs.argtypes = [C.POINTER(WorldCfg)]
+    L.rem2d_world_create.argtypes = [C.POINTER(WorldCfg), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.rem2d_world_destroy.argtypes = [C.c_void_p]
+    L.rem2d_world_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_float]
+    L.rem2d_world_reset.argtypes = [C.c_void_p, C.POINTER(Morph), C.c_void_p]
+    L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
+    L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_int32)]
+    L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
+    L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    if L.rem2d_abi_version() != 1:
+        raise Rem2dError("librem2d.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise Rem2dError("librem2d: error %d: %s" % (rc, lib().rem2d_last_error().decode()))

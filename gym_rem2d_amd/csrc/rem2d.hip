@@ -1,0 +1,1627 @@
+// rem2d.hip -- MI355X (gfx950) batched 2D rigid-body stepper + its C ABI (include/rem2d.h).
+//
+// Replaces the world.Step() hot loop of gym_rem2D's Modular2D.step()/reset()
+// (gym_rem2D/envs/Modular2DEnv.py:565-653; engine semantics: Box2D 2.3.x, SURVEY.md
+// Appendix A) for N independent creatures at once.
+//
+// Execution model (wave64, no MFMA -- this is VALU/latency bound, not a contraction):
+//   * one lane = one rigid body, its revolute joint to the parent body and its contact
+//     list; K = 2..32 consecutive lanes = one creature = one Box2D island; a 64-lane
+//     wavefront (= one workgroup) steps 64/K creatures in lockstep;
+//   * a body's pose/velocity, its joint's effective-mass terms and accumulated impulses and
+//     up to REM2D_SOLVER_SLOTS contact constraints live in VGPRs for a whole launch
+//     (n_steps steps), so HBM is touched once per launch for them;
+//   * contacts only couple a body to static terrain, so all bodies solve their contacts in
+//     parallel; joints couple two lanes and are solved in precomputed rounds that keep
+//     Box2D's island order among joints sharing a body, exchanging body velocities /
+//     positions through a 1.5 KB LDS mailbox -- the result is bit-identical to the sequential
+//     Gauss-Seidel sweep of the CPU restatement;
+//   * the per-body broadphase pair list (edge index, feature keys, warm-start impulses) is
+//     SoA in HBM ([slot][lane], coalesced) and walked with rolled loops.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (every binary32 operation rounded
+// separately, like an x86-64 Box2D build; this is what makes bit-exact parity possible).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rem2d.h"
+
+#define KC REM2D_CONTACT_SLOTS
+#define KT REM2D_SOLVER_SLOTS
+#define WAVE 64
+#define SCR_WORDS 9 // manifold scratch words per solver slot
+
+// ---- b2Settings.h constants (same expressions as Box2D so that they fold identically) ----
+#define B2_PI 3.14159265359f
+#define B2_EPSILON FLT_EPSILON
+#define B2_LINEAR_SLOP 0.005f
+#define B2_ANGULAR_SLOP (2.0f / 180.0f * B2_PI)
+#define B2_POLYGON_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_AABB_EXTENSION 0.1f
+#define B2_AABB_MULTIPLIER 2.0f
+#define B2_MAX_LINEAR_CORRECTION 0.2f
+#define B2_MAX_ANGULAR_CORRECTION (8.0f / 180.0f * B2_PI)
+#define B2_MAX_TRANSLATION 2.0f
+#define B2_MAX_TRANSLATION_SQ (B2_MAX_TRANSLATION * B2_MAX_TRANSLATION)
+#define B2_MAX_ROTATION (0.5f * B2_PI)
+#define B2_MAX_ROTATION_SQ (B2_MAX_ROTATION * B2_MAX_ROTATION)
+#define B2_BAUMGARTE 0.2f
+#define B2_TIME_TO_SLEEP 0.5f
+#define B2_LINEAR_SLEEP_TOL 0.01f
+#define B2_ANGULAR_SLEEP_TOL (2.0f / 180.0f * B2_PI)
+
+enum { SHAPE_NONE = 0, SHAPE_BOX = 1, SHAPE_CIRCLE = 2 };
+enum { MF_CIRCLES = 0, MF_FACE_A = 1, MF_FACE_B = 2 };
+enum { LIM_INACTIVE = 0, LIM_AT_LOWER = 1, LIM_AT_UPPER = 2, LIM_EQUAL = 3 };
+enum { CF_VERTEX = 0, CF_FACE = 1 };
+
+// =====================================================================================
+// state arena
+// =====================================================================================
+struct FieldDesc { int kind; int dtype; }; // kind: 0 per lane, 1 per contact slot x lane, 2 per creature
+static const FieldDesc kFields[REM2D_F_COUNT] = {
+    // per lane float (27)
+    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
+    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
+    // per lane int (6)
+    {0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1},
+    // per lane double (5)
+    {0, 2}, {0, 2}, {0, 2}, {0, 2}, {0, 2},
+    // contact slots (8): edge, info (int), key0, key1 (int), n0 n1 t0 t1 (float)
+    {1, 1}, {1, 1}, {1, 1}, {1, 1}, {1, 0}, {1, 0}, {1, 0}, {1, 0},
+    // per creature: wod f64, fitness f64, reward f32, done, everdone, frozen, steps i32, invdt0 f32, newfix, err,
+    // positers, toievents i32
+    {2, 2}, {2, 2}, {2, 0}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 0}, {2, 1}, {2, 1}, {2, 1}, {2, 1}};
+
+struct Layout {
+    int Np, Lp, K;
+    size_t off[REM2D_F_COUNT];
+    size_t count[REM2D_F_COUNT];
+    size_t total;
+};
+static Layout make_layout(const rem2d_world_cfg *cfg) {
+    Layout L;
+    int perWave = WAVE / cfg->lanes;
+    L.K = cfg->lanes;
+    L.Np = (cfg->n_envs + perWave - 1) / perWave * perWave;
+    L.Lp = L.Np * cfg->lanes;
+    size_t o = 0;
+    // 8-byte fields first so that everything stays naturally aligned
+    for (int pass = 0; pass < 2; ++pass)
+        for (int f = 0; f < REM2D_F_COUNT; ++f) {
+            bool wide = kFields[f].dtype == 2;
+            if ((pass == 0) != wide) continue;
+            size_t n = kFields[f].kind == 0 ? (size_t)L.Lp : kFields[f].kind == 1 ? (size_t)L.Lp * KC : (size_t)L.Np;
+            L.off[f] = o;
+            L.count[f] = n;
+            o += n * (wide ? 8 : 4);
+            o = (o + 255) & ~(size_t)255;
+        }
+    L.total = o;
+    return L;
+}
+
+struct Terrain {
+    int nEdge, nPoly;
+    const float *v1x, *v1y, *v2x, *v2y; // edge end points (world frame; terrain bodies sit at the origin)
+    const float *flx, *fly, *fux, *fuy; // fat AABB of every edge proxy
+    float x0, invPitch;
+    float friction; // b2MixFriction(terrain, module)
+};
+
+struct State {
+    float *px, *py, *ang, *vx, *vy, *w, *sleepT, *hx, *hy, *invM, *invI, *fatLx, *fatLy, *fatUx, *fatUy;
+    float *jAx, *jAy, *jBx, *jBy, *jTorque, *jLower, *jUpper, *jImpX, *jImpY, *jImpZ, *jMotorImp, *jMotorSpeed;
+    int *shape, *parent, *jround, *awake, *jLimit, *cCount;
+    double *cAmp, *cPhase, *cFreq, *cOffset, *cIstate;
+    int *cEdge, *cInfo;
+    unsigned *cKey0, *cKey1;
+    float *cN0, *cN1, *cT0, *cT1;
+    double *wod, *fitness;
+    float *reward;
+    int *done, *everDone, *frozen, *steps;
+    float *invDt0;
+    int *newFix, *err, *posIters, *toiEvents;
+    float *scr; // handle-owned manifold scratch [KT*SCR_WORDS][Lp]
+    int Lp, Np, nEnvs;
+    unsigned flags;
+};
+
+// =====================================================================================
+// device math (b2Math.h operand order)
+// =====================================================================================
+struct V2 { float x, y; };
+#define DEV __device__ __forceinline__
+DEV V2 mk(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+DEV V2 vadd(V2 a, V2 b) { return mk(a.x + b.x, a.y + b.y); }
+DEV V2 vsub(V2 a, V2 b) { return mk(a.x - b.x, a.y - b.y); }
+DEV V2 vneg(V2 a) { return mk(-a.x, -a.y); }
+DEV V2 vscale(float s, V2 a) { return mk(s * a.x, s * a.y); }
+DEV float vdot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+DEV float vcross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+DEV V2 vcross_vs(V2 a, float s) { return mk(s * a.y, -s * a.x); }
+DEV V2 vcross_sv(float s, V2 a) { return mk(-s * a.y, s * a.x); }
+DEV float vlen(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
+DEV float vdist2(V2 a, V2 b) { V2 c = vsub(a, b); return vdot(c, c); }
+DEV float fmin32(float a, float b) { return a < b ? a : b; }
+DEV float fmax32(float a, float b) { return a > b ? a : b; }
+DEV float fabs32(float a) { return a > 0.0f ? a : -a; }
+DEV float fclamp(float a, float lo, float hi) { return fmax32(lo, fmin32(a, hi)); }
+DEV V2 vmin2(V2 a, V2 b) { return mk(fmin32(a.x, b.x), fmin32(a.y, b.y)); }
+DEV V2 vmax2(V2 a, V2 b) { return mk(fmax32(a.x, b.x), fmax32(a.y, b.y)); }
+DEV float vnormalize(V2 &a) {
+    float length = vlen(a);
+    if (length < B2_EPSILON) return 0.0f;
+    float inv = 1.0f / length;
+    a.x *= inv;
+    a.y *= inv;
+    return length;
+}
+struct Rot { float s, c; };
+DEV V2 rmul(Rot q, V2 v) { return mk(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
+DEV V2 rmulT(Rot q, V2 v) { return mk(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
+DEV V2 xmul(Rot q, V2 p, V2 v) {
+    float x = (q.c * v.x - q.s * v.y) + p.x;
+    float y = (q.s * v.x + q.c * v.y) + p.y;
+    return mk(x, y);
+}
+DEV V2 xmulT(Rot q, V2 p, V2 v) {
+    float px = v.x - p.x, py = v.y - p.y;
+    return mk(q.c * px + q.s * py, -q.s * px + q.c * py);
+}
+
+// ---- trig: the algorithm documented in DESIGN.md ("rem2d trig"), binary64 without FMA ----
+DEV void dev_sincos_d(double x, double &s, double &c) {
+    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
+                 PIO2_1T = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double fn = rint(x * INV_PIO2);
+    int n = (int)fn;
+    double r = (x - fn * PIO2_1) - fn * PIO2_1T;
+    double z = r * r;
+    double ps = r + r * (z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))))));
+    double pc = (1.0 - 0.5 * z) + z * z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    int q = n & 3;
+    double ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    s = (q == 2 || q == 3) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+DEV Rot rot_set(float a) {
+    double s, c;
+    dev_sincos_d((double)a, s, c);
+    Rot q;
+    q.s = (float)s;
+    q.c = (float)c;
+    return q;
+}
+DEV double dev_sin(double x) {
+    double s, c;
+    dev_sincos_d(x, s, c);
+    return s;
+}
+
+// ---- K-lane group reductions (K consecutive lanes = one creature) ----
+template <int K> DEV float group_min(float v) {
+#pragma unroll
+    for (int o = 1; o < K; o <<= 1) {
+        float t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+template <int K> DEV int group_and(int v) {
+#pragma unroll
+    for (int o = 1; o < K; o <<= 1) v &= __shfl_xor(v, o);
+    return v;
+}
+template <int K> DEV int group_or(int v) {
+#pragma unroll
+    for (int o = 1; o < K; o <<= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+DEV int wave_max(int v) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// =====================================================================================
+// narrowphase (terrain body A is static at the origin: xfA = identity)
+// =====================================================================================
+struct Manifold {
+    int type, count;
+    V2 ln, lp, p0, p1;
+    unsigned k0, k1;
+};
+DEV unsigned mkkey(int indexA, int indexB, int typeA, int typeB) {
+    return (unsigned)indexA | ((unsigned)indexB << 8) | ((unsigned)typeA << 16) | ((unsigned)typeB << 24);
+}
+
+// b2CollideEdgeAndCircle (circle m_p = 0)
+DEV void collide_edge_circle(Manifold &m, V2 A, V2 B, float rB, V2 center) {
+    m.count = 0;
+    m.type = MF_CIRCLES;
+    m.ln = mk(0.0f, 0.0f);
+    m.lp = mk(0.0f, 0.0f);
+    m.p0 = mk(0.0f, 0.0f);
+    m.p1 = mk(0.0f, 0.0f);
+    m.k0 = m.k1 = 0u;
+    V2 Q = center;
+    V2 e = vsub(B, A);
+    float u = vdot(e, vsub(B, Q));
+    float v = vdot(e, vsub(Q, A));
+    float radius = B2_POLYGON_RADIUS + rB;
+    if (v <= 0.0f) {
+        V2 d = vsub(Q, A);
+        float dd = vdot(d, d);
+        if (dd > radius * radius) return;
+        m.count = 1;
+        m.type = MF_CIRCLES;
+        m.lp = A;
+        m.k0 = mkkey(0, 0, CF_VERTEX, CF_VERTEX);
+        return;
+    }
+    if (u <= 0.0f) {
+        V2 d = vsub(Q, B);
+        float dd = vdot(d, d);
+        if (dd > radius * radius) return;
+        m.count = 1;
+        m.type = MF_CIRCLES;
+        m.lp = B;
+        m.k0 = mkkey(1, 0, CF_VERTEX, CF_VERTEX);
+        return;
+    }
+    float den = vdot(e, e);
+    V2 P = vscale(1.0f / den, vadd(vscale(u, A), vscale(v, B)));
+    V2 d = vsub(Q, P);
+    float dd = vdot(d, d);
+    if (dd > radius * radius) return;
+    V2 n = mk(-e.y, e.x);
+    if (vdot(n, vsub(Q, A)) < 0.0f) n = mk(-n.x, -n.y);
+    vnormalize(n);
+    m.count = 1;
+    m.type = MF_FACE_A;
+    m.ln = n;
+    m.lp = A;
+    m.k0 = mkkey(0, 0, CF_FACE, CF_VERTEX);
+}
+
+struct ClipV { V2 v; int iA, iB, tA, tB; };
+DEV int clip_segment(ClipV (&out)[2], const ClipV (&in)[2], V2 normal, float offset, int vertexIndexA) {
+    int numOut = 0;
+    float distance0 = vdot(normal, in[0].v) - offset;
+    float distance1 = vdot(normal, in[1].v) - offset;
+    ClipV o0 = in[0], o1 = in[1];
+    bool k0 = distance0 <= 0.0f, k1 = distance1 <= 0.0f;
+    // compact without dynamic indexing
+    if (k0 && k1) { out[0] = o0; out[1] = o1; numOut = 2; }
+    else if (k0) { out[0] = o0; out[1] = o0; numOut = 1; }
+    else if (k1) { out[0] = o1; out[1] = o1; numOut = 1; }
+    else { out[0] = o0; out[1] = o0; numOut = 0; }
+    if (distance0 * distance1 < 0.0f) {
+        float interp = distance0 / (distance0 - distance1);
+        ClipV x;
+        x.v = vadd(in[0].v, vscale(interp, vsub(in[1].v, in[0].v)));
+        x.iA = vertexIndexA & 0xff;
+        x.iB = in[0].iB;
+        x.tA = CF_VERTEX;
+        x.tB = CF_FACE;
+        if (numOut == 0) out[0] = x; else out[1] = x; // numOut is 0 or 1 here
+        ++numOut;
+    }
+    return numOut;
+}
+DEV V2 sel4(const V2 (&a)[4], int i) {
+    V2 r = a[0];
+    r = i == 1 ? a[1] : r;
+    r = i == 2 ? a[2] : r;
+    r = i == 3 ? a[3] : r;
+    return r;
+}
+// b2EPCollider::Collide for an isolated edge and a SetAsBox polygon (centroid 0, radius 0.01)
+DEV void collide_edge_box(Manifold &m, V2 v1, V2 v2, float hx, float hy, V2 p, Rot q) {
+    m.count = 0;
+    m.type = MF_FACE_A;
+    m.ln = mk(0.0f, 0.0f);
+    m.lp = mk(0.0f, 0.0f);
+    m.p0 = mk(0.0f, 0.0f);
+    m.p1 = mk(0.0f, 0.0f);
+    m.k0 = m.k1 = 0u;
+    const V2 vloc[4] = {mk(-hx, -hy), mk(hx, -hy), mk(hx, hy), mk(-hx, hy)};
+    const V2 nloc[4] = {mk(0.0f, -1.0f), mk(1.0f, 0.0f), mk(0.0f, 1.0f), mk(-1.0f, 0.0f)};
+    V2 centroidB = xmul(q, p, mk(0.0f, 0.0f));
+    V2 edge1 = vsub(v2, v1);
+    vnormalize(edge1);
+    V2 normal1 = mk(edge1.y, -edge1.x);
+    float offset1 = vdot(normal1, vsub(centroidB, v1));
+    bool front = offset1 >= 0.0f;
+    V2 normal = front ? normal1 : vneg(normal1);
+    V2 limit = front ? vneg(normal1) : normal1; // lowerLimit == upperLimit for an isolated edge
+    V2 pv[4], pn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pv[i] = xmul(q, p, vloc[i]);
+        pn[i] = rmul(q, nloc[i]);
+    }
+    const float radius = 2.0f * B2_POLYGON_RADIUS;
+    float edgeSep = FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = vdot(normal, vsub(pv[i], v1));
+        if (s < edgeSep) edgeSep = s;
+    }
+    if (edgeSep > radius) return;
+    // ComputePolygonSeparation
+    int polyIndex = -1;
+    float polySep = -FLT_MAX;
+    bool separated = false;
+    V2 perp = mk(-normal.y, normal.x);
+    (void)perp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V2 n = vneg(pn[i]);
+        float s1 = vdot(n, vsub(pv[i], v1));
+        float s2 = vdot(n, vsub(pv[i], v2));
+        float s = fmin32(s1, s2);
+        if (s > radius) separated = true; // first such axis ends the search with "no collision"
+        // adjacency filter: lower == upper limit, so both branches test the same expression
+        bool skip = vdot(vsub(n, limit), normal) < -B2_ANGULAR_SLOP;
+        if (!separated && !skip && s > polySep) {
+            polyIndex = i;
+            polySep = s;
+        }
+    }
+    if (separated) return;
+    bool polyValid = polyIndex >= 0;
+    const float k_relativeTol = 0.98f, k_absoluteTol = 0.001f;
+    bool primaryIsPoly = polyValid && (polySep > k_relativeTol * edgeSep + k_absoluteTol);
+    ClipV ie[2];
+    int rf_i1, rf_i2;
+    V2 rf_v1, rf_v2, rf_normal;
+    if (!primaryIsPoly) {
+        m.type = MF_FACE_A;
+        int bestIndex = 0;
+        float bestValue = vdot(normal, pn[0]);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            float value = vdot(normal, pn[i]);
+            if (value < bestValue) { bestValue = value; bestIndex = i; }
+        }
+        int i1 = bestIndex, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
+        ie[0].v = sel4(pv, i1); ie[0].iA = 0; ie[0].iB = i1; ie[0].tA = CF_FACE; ie[0].tB = CF_VERTEX;
+        ie[1].v = sel4(pv, i2); ie[1].iA = 0; ie[1].iB = i2; ie[1].tA = CF_FACE; ie[1].tB = CF_VERTEX;
+        if (front) { rf_i1 = 0; rf_i2 = 1; rf_v1 = v1; rf_v2 = v2; rf_normal = normal1; }
+        else { rf_i1 = 1; rf_i2 = 0; rf_v1 = v2; rf_v2 = v1; rf_normal = vneg(normal1); }
+    } else {
+        m.type = MF_FACE_B;
+        ie[0].v = v1; ie[0].iA = 0; ie[0].iB = polyIndex; ie[0].tA = CF_VERTEX; ie[0].tB = CF_FACE;
+        ie[1].v = v2; ie[1].iA = 0; ie[1].iB = polyIndex; ie[1].tA = CF_VERTEX; ie[1].tB = CF_FACE;
+        rf_i1 = polyIndex;
+        rf_i2 = rf_i1 + 1 < 4 ? rf_i1 + 1 : 0;
+        rf_v1 = sel4(pv, rf_i1);
+        rf_v2 = sel4(pv, rf_i2);
+        rf_normal = sel4(pn, rf_i1);
+    }
+    V2 sideNormal1 = mk(rf_normal.y, -rf_normal.x);
+    V2 sideNormal2 = vneg(sideNormal1);
+    float sideOffset1 = vdot(sideNormal1, rf_v1);
+    float sideOffset2 = vdot(sideNormal2, rf_v2);
+    ClipV c1[2], c2[2];
+    int np = clip_segment(c1, ie, sideNormal1, sideOffset1, rf_i1);
+    if (np < 2) return;
+    np = clip_segment(c2, c1, sideNormal2, sideOffset2, rf_i2);
+    if (np < 2) return;
+    if (!primaryIsPoly) {
+        m.ln = rf_normal;
+        m.lp = rf_v1;
+    } else {
+        m.ln = sel4(nloc, rf_i1);
+        m.lp = sel4(vloc, rf_i1);
+    }
+    int pointCount = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float separation = vdot(rf_normal, vsub(c2[i].v, rf_v1));
+        if (separation <= radius) {
+            V2 lp;
+            unsigned key;
+            if (!primaryIsPoly) {
+                lp = xmulT(q, p, c2[i].v);
+                key = mkkey(c2[i].iA, c2[i].iB, c2[i].tA, c2[i].tB);
+            } else {
+                lp = c2[i].v;
+                key = mkkey(c2[i].iB, c2[i].iA, c2[i].tB, c2[i].tA);
+            }
+            if (pointCount == 0) { m.p0 = lp; m.k0 = key; }
+            else { m.p1 = lp; m.k1 = key; }
+            ++pointCount;
+        }
+    }
+    m.count = pointCount;
+}
+
+// =====================================================================================
+// shape AABBs (b2PolygonShape/b2CircleShape::ComputeAABB)
+// =====================================================================================
+struct AABB { V2 lo, hi; };
+DEV AABB body_aabb(int shape, float hx, float hy, V2 p, Rot q) {
+    AABB bb;
+    if (shape == SHAPE_BOX) {
+        V2 lower = xmul(q, p, mk(-hx, -hy)), upper = lower;
+        V2 v = xmul(q, p, mk(hx, -hy));
+        lower = vmin2(lower, v); upper = vmax2(upper, v);
+        v = xmul(q, p, mk(hx, hy));
+        lower = vmin2(lower, v); upper = vmax2(upper, v);
+        v = xmul(q, p, mk(-hx, hy));
+        lower = vmin2(lower, v); upper = vmax2(upper, v);
+        V2 r = mk(B2_POLYGON_RADIUS, B2_POLYGON_RADIUS);
+        bb.lo = vsub(lower, r);
+        bb.hi = vadd(upper, r);
+    } else {
+        V2 c = vadd(p, rmul(q, mk(0.0f, 0.0f)));
+        bb.lo = mk(c.x - hx, c.y - hx);
+        bb.hi = mk(c.x + hx, c.y + hx);
+    }
+    return bb;
+}
+DEV bool aabb_overlap(V2 alo, V2 ahi, V2 blo, V2 bhi) {
+    V2 d1 = vsub(blo, ahi), d2 = vsub(alo, bhi);
+    if (d1.x > 0.0f || d1.y > 0.0f) return false;
+    if (d2.x > 0.0f || d2.y > 0.0f) return false;
+    return true;
+}
+
+// =====================================================================================
+// per-lane solver structures (registers)
+// =====================================================================================
+struct ContactC { // one touching contact (terrain A static, body B = this lane)
+    V2 normal;
+    V2 rB0, rB1;
+    float nm0, nm1, tm0, tm1; // normalMass / tangentMass per point
+    float n0, n1, t0, t1;     // accumulated impulses
+    float k11, k12, k22;      // K
+    float i11, i12, i22;      // normalMass = K^-1 (symmetric)
+    int count;                // solver point count (block solver may drop to 1)
+};
+
+// b2ContactManager::AddPair: head-insert into the body's pair list
+DEV void pairs_insert_front(const State &S, int gl, int &count, int edge, int &err) {
+    if (count >= KC) { err |= REM2D_ERR_PAIR_OVERFLOW; return; }
+    for (int s = count; s > 0; --s) {
+        size_t d = (size_t)s * S.Lp + gl, f = (size_t)(s - 1) * S.Lp + gl;
+        S.cEdge[d] = S.cEdge[f];
+        S.cInfo[d] = S.cInfo[f];
+        S.cKey0[d] = S.cKey0[f];
+        S.cKey1[d] = S.cKey1[f];
+        S.cN0[d] = S.cN0[f];
+        S.cN1[d] = S.cN1[f];
+        S.cT0[d] = S.cT0[f];
+        S.cT1[d] = S.cT1[f];
+    }
+    S.cEdge[gl] = edge;
+    S.cInfo[gl] = 0;
+    S.cKey0[gl] = 0u;
+    S.cKey1[gl] = 0u;
+    S.cN0[gl] = 0.0f;
+    S.cN1[gl] = 0.0f;
+    S.cT0[gl] = 0.0f;
+    S.cT1[gl] = 0.0f;
+    ++count;
+}
+DEV void pairs_remove(const State &S, int gl, int &count, int s) {
+    for (int k = s; k + 1 < count; ++k) {
+        size_t d = (size_t)k * S.Lp + gl, f = (size_t)(k + 1) * S.Lp + gl;
+        S.cEdge[d] = S.cEdge[f];
+        S.cInfo[d] = S.cInfo[f];
+        S.cKey0[d] = S.cKey0[f];
+        S.cKey1[d] = S.cKey1[f];
+        S.cN0[d] = S.cN0[f];
+        S.cN1[d] = S.cN1[f];
+        S.cT0[d] = S.cT0[f];
+        S.cT1[d] = S.cT1[f];
+    }
+    --count;
+    S.cEdge[(size_t)count * S.Lp + gl] = -1;
+}
+// b2BroadPhase::UpdatePairs for one moved body proxy: new pairs in ascending edge (= proxy id) order
+DEV void find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2 flo, V2 fhi, int &err) {
+    int lo = (int)floorf((flo.x - 0.25f - T.x0) * T.invPitch) - 1;
+    int hi = (int)floorf((fhi.x + 0.25f - T.x0) * T.invPitch) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > T.nEdge - 1 ? T.nEdge - 1 : hi;
+    for (int e = lo; e <= hi; ++e) {
+        if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), flo, fhi)) continue;
+        bool exists = false;
+        for (int s = 0; s < count; ++s) exists |= (S.cEdge[(size_t)s * S.Lp + gl] == e);
+        if (!exists) pairs_insert_front(S, gl, count, e, err);
+    }
+}
+
+// =====================================================================================
+// the step kernel
+// =====================================================================================
+struct StepArgs { int nSteps; float dt; int velIters, posIters; };
+
+template <int K>
+__global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
+    __shared__ volatile float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
+    const int lane = threadIdx.x;
+    const int gl = blockIdx.x * WAVE + lane;
+    const int env = gl / K;
+    const int base = lane & ~(K - 1);
+    const int sub = lane & (K - 1);
+    const size_t Lp = (size_t)S.Lp;
+
+    // ---- load per-lane state ----
+    const int shape = S.shape[gl];
+    const bool active = shape != SHAPE_NONE;
+    const float hx = S.hx[gl], hy = S.hy[gl], mB = S.invM[gl], iB = S.invI[gl];
+    const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
+    float px = S.px[gl], py = S.py[gl], ang = S.ang[gl], vx = S.vx[gl], vy = S.vy[gl], w = S.w[gl];
+    float sleepT = S.sleepT[gl];
+    int awake = S.awake[gl];
+    V2 fatLo = mk(S.fatLx[gl], S.fatLy[gl]), fatHi = mk(S.fatUx[gl], S.fatUy[gl]);
+    int cCount = S.cCount[gl];
+    // joint (this lane = body B, parent lane = body A)
+    const int parent = S.parent[gl];
+    const bool hasJoint = active && parent >= 0;
+    const int pl = base + (parent >= 0 ? parent : 0);
+    const V2 anchorA = mk(S.jAx[gl], S.jAy[gl]), anchorB = mk(S.jBx[gl], S.jBy[gl]);
+    const float jTorque = S.jTorque[gl], jLower = S.jLower[gl], jUpper = S.jUpper[gl];
+    const int jround = hasJoint ? S.jround[gl] : -1;
+    float impX = S.jImpX[gl], impY = S.jImpY[gl], impZ = S.jImpZ[gl], motorImp = S.jMotorImp[gl];
+    int limitState = S.jLimit[gl];
+    float motorSpeed = S.jMotorSpeed[gl];
+    const double cAmp = S.cAmp[gl], cPhase = S.cPhase[gl], cFreq = S.cFreq[gl], cOffset = S.cOffset[gl];
+    double cIstate = S.cIstate[gl];
+    const float mA = __shfl(mB, pl), iA = __shfl(iB, pl);
+    const int nRounds = wave_max(jround) + 1;
+    // does any lane of this creature hang off me?  (SetMotorSpeed wakes both bodies)
+    int childMask = 0;
+    {
+        int pm = hasJoint ? (1 << parent) : 0;
+        childMask = group_or<K>(pm);
+    }
+    const bool jointed = hasJoint || ((childMask >> sub) & 1);
+    // per-creature scalars (every lane keeps a copy)
+    double wod = S.wod[env], fitness = S.fitness[env];
+    float invDt0 = S.invDt0[env];
+    int newFix = S.newFix[env], err = 0, frozen = S.frozen[env], stepIdx = S.steps[env];
+    int done = S.done[env], everDone = S.everDone[env], lastPosIters = S.posIters[env];
+    float reward = S.reward[env];
+
+    const float h = A.dt;
+    const float inv_dt = h > 0.0f ? 1.0f / h : 0.0f;
+    const float friction = T.friction;
+    const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
+    const bool allowSleep = (S.flags & REM2D_FLAG_NO_SLEEP) == 0;
+
+    for (int step = 0; step < A.nSteps; ++step) {
+        // =============== Modular2D.step: wod, controllers, PID -> motorSpeed ===============
+        wod += 0.04;
+        {
+            float angParent = __shfl(ang, pl);
+            if (hasJoint) {
+                cIstate += cFreq;
+                double target = (cAmp * dev_sin(cIstate + cPhase)) + cOffset;
+                float jointAngle = ang - angParent - 0.0f;
+                double speed = (target - (double)jointAngle) * 1.9;
+                motorSpeed = (float)speed;
+            }
+            if (active && jointed) { // b2RevoluteJoint::SetMotorSpeed -> SetAwake(true) on both bodies
+                if (sleepResetAlways || !awake) sleepT = 0.0f;
+                awake = 1;
+            }
+        }
+        // =============== b2World::Step ===============
+        const float dtRatio = invDt0 * h;
+        if (newFix) { // FindNewContacts for freshly created fixtures
+            if (active) find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err);
+            newFix = 0;
+        }
+        Rot q = rot_set(ang); // body transform m_xf (q from sweep.a, p = c since localCenter = 0)
+        // ---- b2ContactManager::Collide: destroy separated pairs, update manifolds ----
+        int nTouch = 0;
+        unsigned slotPack = 0u;
+        if (active && awake) {
+            int s = 0;
+            while (s < cCount) {
+                size_t o = (size_t)s * Lp + gl;
+                int e = S.cEdge[o];
+                if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), fatLo, fatHi)) {
+                    pairs_remove(S, gl, cCount, s);
+                    continue;
+                }
+                Manifold m;
+                V2 e1 = mk(T.v1x[e], T.v1y[e]), e2 = mk(T.v2x[e], T.v2y[e]);
+                if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, mk(px, py), q);
+                else collide_edge_circle(m, e1, e2, hx, mk(px, py));
+                // b2Contact::Update: carry impulses over by feature id
+                int oldCount = S.cInfo[o] & 0xff;
+                unsigned ok0 = S.cKey0[o], ok1 = S.cKey1[o];
+                float on0 = S.cN0[o], on1 = S.cN1[o], ot0 = S.cT0[o], ot1 = S.cT1[o];
+                float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
+                if (m.count > 0) {
+                    if (oldCount > 0 && ok0 == m.k0) { n0 = on0; t0 = ot0; }
+                    else if (oldCount > 1 && ok1 == m.k0) { n0 = on1; t0 = ot1; }
+                }
+                if (m.count > 1) {
+                    if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
+                    else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
+                }
+                S.cInfo[o] = m.count | (m.type << 8);
+                S.cKey0[o] = m.k0;
+                S.cKey1[o] = m.k1;
+                S.cN0[o] = n0;
+                S.cN1[o] = n1;
+                S.cT0[o] = t0;
+                S.cT1[o] = t1;
+                if (m.count > 0) {
+                    if (nTouch < KT) {
+                        float *sc = S.scr + (size_t)nTouch * SCR_WORDS * Lp + gl;
+                        sc[0 * Lp] = __int_as_float(m.type | (m.count << 8));
+                        sc[1 * Lp] = m.ln.x;
+                        sc[2 * Lp] = m.ln.y;
+                        sc[3 * Lp] = m.lp.x;
+                        sc[4 * Lp] = m.lp.y;
+                        sc[5 * Lp] = m.p0.x;
+                        sc[6 * Lp] = m.p0.y;
+                        sc[7 * Lp] = m.p1.x;
+                        sc[8 * Lp] = m.p1.y;
+                        slotPack |= (unsigned)s << (4 * nTouch);
+                        ++nTouch;
+                    } else {
+                        err |= REM2D_ERR_SOLVER_OVERFLOW;
+                    }
+                }
+                ++s;
+            }
+        }
+        // =============== b2World::Solve ===============
+        // the creature is one island; it is simulated iff any of its bodies is awake
+        const int envAwake = group_or<K>(active && awake ? 1 : 0);
+        float c0x = px, c0y = py, a0 = ang;
+        bool moved = false;
+        if (envAwake) {
+            if (active && !awake) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
+            // ---- integrate velocities (gravity (0,-10), no forces, no damping) ----
+            if (active) {
+                V2 acc = vadd(vscale(1.0f, mk(0.0f, -10.0f)), vscale(mB, mk(0.0f, 0.0f)));
+                V2 v = vadd(mk(vx, vy), vscale(h, acc));
+                float wz = w + h * iB * 0.0f;
+                v = vscale(1.0f / (1.0f + h * 0.0f), v);
+                wz *= 1.0f / (1.0f + h * 0.0f);
+                vx = v.x; vy = v.y; w = wz;
+            }
+            // ---- contact constraints: b2ContactSolver ctor + InitializeVelocityConstraints ----
+            ContactC cc[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                cc[t].count = 0;
+                if (t < nTouch) {
+                    const float *sc = S.scr + (size_t)t * SCR_WORDS * Lp + gl;
+                    int tc = __float_as_int(sc[0]);
+                    int mtype = tc & 0xff, mcount = tc >> 8;
+                    V2 ln = mk(sc[1 * Lp], sc[2 * Lp]), lp = mk(sc[3 * Lp], sc[4 * Lp]);
+                    V2 p0 = mk(sc[5 * Lp], sc[6 * Lp]), p1 = mk(sc[7 * Lp], sc[8 * Lp]);
+                    int ps = (slotPack >> (4 * t)) & 0xf;
+                    size_t o = (size_t)ps * Lp + gl;
+                    ContactC &c = cc[t];
+                    c.count = mcount;
+                    c.n0 = dtRatio * S.cN0[o];
+                    c.t0 = dtRatio * S.cT0[o];
+                    c.n1 = dtRatio * S.cN1[o];
+                    c.t1 = dtRatio * S.cT1[o];
+                    // b2WorldManifold::Initialize with xfA = identity, radiusA = polygonRadius
+                    V2 cB = mk(px, py);
+                    V2 normal, w0, w1 = mk(0.0f, 0.0f);
+                    const float radiusA = B2_POLYGON_RADIUS;
+                    if (mtype == MF_CIRCLES) {
+                        normal = mk(1.0f, 0.0f);
+                        V2 pointA = lp;
+                        V2 pointB = xmul(q, cB, p0);
+                        if (vdist2(pointA, pointB) > B2_EPSILON * B2_EPSILON) {
+                            normal = vsub(pointB, pointA);
+                            vnormalize(normal);
+                        }
+                        V2 cA = vadd(pointA, vscale(radiusA, normal));
+                        V2 cBp = vsub(pointB, vscale(radiusB, normal));
+                        w0 = vscale(0.5f, vadd(cA, cBp));
+                    } else if (mtype == MF_FACE_A) {
+                        normal = ln;
+                        V2 planePoint = lp;
+                        V2 clip = xmul(q, cB, p0);
+                        V2 cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
+                        V2 cBp = vsub(clip, vscale(radiusB, normal));
+                        w0 = vscale(0.5f, vadd(cA, cBp));
+                        if (mcount > 1) {
+                            clip = xmul(q, cB, p1);
+                            cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
+                            cBp = vsub(clip, vscale(radiusB, normal));
+                            w1 = vscale(0.5f, vadd(cA, cBp));
+                        }
+                    } else {
+                        V2 nB = rmul(q, ln);
+                        V2 planePoint = xmul(q, cB, lp);
+                        V2 clip = p0;
+                        V2 cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
+                        V2 cA = vsub(clip, vscale(radiusA, nB));
+                        w0 = vscale(0.5f, vadd(cA, cBp));
+                        if (mcount > 1) {
+                            clip = p1;
+                            cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
+                            cA = vsub(clip, vscale(radiusA, nB));
+                            w1 = vscale(0.5f, vadd(cA, cBp));
+                        }
+                        normal = vneg(nB);
+                    }
+                    c.normal = normal;
+                    V2 tangent = vcross_vs(normal, 1.0f);
+                    c.rB0 = vsub(w0, cB);
+                    c.rB1 = vsub(w1, cB);
+                    {
+                        float rnB = vcross(c.rB0, normal);
+                        float kNormal = mB + iB * rnB * rnB;
+                        c.nm0 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+                        float rtB = vcross(c.rB0, tangent);
+                        float kTangent = mB + iB * rtB * rtB;
+                        c.tm0 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+                    }
+                    c.nm1 = c.tm1 = 0.0f;
+                    c.k11 = c.k12 = c.k22 = c.i11 = c.i12 = c.i22 = 0.0f;
+                    if (mcount > 1) {
+                        float rnB = vcross(c.rB1, normal);
+                        float kNormal = mB + iB * rnB * rnB;
+                        c.nm1 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+                        float rtB = vcross(c.rB1, tangent);
+                        float kTangent = mB + iB * rtB * rtB;
+                        c.tm1 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+                        float rn1B = vcross(c.rB0, normal), rn2B = vcross(c.rB1, normal);
+                        float k11 = mB + iB * rn1B * rn1B;
+                        float k22 = mB + iB * rn2B * rn2B;
+                        float k12 = mB + iB * rn1B * rn2B;
+                        const float k_maxConditionNumber = 1000.0f;
+                        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+                            c.k11 = k11; c.k12 = k12; c.k22 = k22;
+                            float det = k11 * k22 - k12 * k12;
+                            if (det != 0.0f) det = 1.0f / det;
+                            c.i11 = det * k22;
+                            c.i12 = -det * k12;
+                            c.i22 = det * k11;
+                        } else {
+                            c.count = 1;
+                        }
+                    }
+                    // ---- WarmStart ----
+                    {
+                        V2 P = vadd(vscale(c.n0, normal), vscale(c.t0, tangent));
+                        w += iB * vcross(c.rB0, P);
+                        vx += mB * P.x; vy += mB * P.y;
+                        if (c.count > 1) {
+                            P = vadd(vscale(c.n1, normal), vscale(c.t1, tangent));
+                            w += iB * vcross(c.rB1, P);
+                            vx += mB * P.x; vy += mB * P.y;
+                        }
+                    }
+                }
+            }
+            // ---- joints: InitVelocityConstraints (warm start), in island rounds ----
+            V2 rA = mk(0.0f, 0.0f), rB = mk(0.0f, 0.0f);
+            float m_exx = 0.0f, m_eyx = 0.0f, m_ezx = 0.0f, m_eyy = 0.0f, m_ezy = 0.0f, m_ezz = 0.0f, motorMass = 0.0f;
+            float det33 = 0.0f, det22 = 0.0f, cyz_x = 0.0f, cyz_y = 0.0f, cyz_z = 0.0f;
+            const float maxMotorImpulse = h * jTorque;
+            {
+                float sA = __shfl(q.s, pl), cA = __shfl(q.c, pl);
+                float aA = __shfl(ang, pl);
+                if (hasJoint) {
+                    Rot qA; qA.s = sA; qA.c = cA;
+                    rA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
+                    rB = rmul(q, vsub(anchorB, mk(0.0f, 0.0f)));
+                    m_exx = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+                    m_eyx = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+                    m_ezx = -rA.y * iA - rB.y * iB;
+                    m_eyy = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+                    m_ezy = rA.x * iA + rB.x * iB;
+                    m_ezz = iA + iB;
+                    motorMass = iA + iB;
+                    if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+                    float jointAngle = ang - aA - 0.0f;
+                    if (fabs32(jUpper - jLower) < 2.0f * B2_ANGULAR_SLOP) {
+                        limitState = LIM_EQUAL;
+                    } else if (jointAngle <= jLower) {
+                        if (limitState != LIM_AT_LOWER) impZ = 0.0f;
+                        limitState = LIM_AT_LOWER;
+                    } else if (jointAngle >= jUpper) {
+                        if (limitState != LIM_AT_UPPER) impZ = 0.0f;
+                        limitState = LIM_AT_UPPER;
+                    } else {
+                        limitState = LIM_INACTIVE;
+                        impZ = 0.0f;
+                    }
+                    impX *= dtRatio; impY *= dtRatio; impZ *= dtRatio; motorImp *= dtRatio;
+                    // loop invariants of b2Mat33::Solve33 / Solve22 (same expressions, evaluated once)
+                    // ex = (m_exx, m_eyx, m_ezx), ey = (m_eyx, m_eyy, m_ezy), ez = (m_ezx, m_ezy, m_ezz)
+                    cyz_x = m_eyy * m_ezz - m_ezy * m_ezy;
+                    cyz_y = m_ezy * m_ezx - m_eyx * m_ezz;
+                    cyz_z = m_eyx * m_ezy - m_eyy * m_ezx;
+                    det33 = m_exx * cyz_x + m_eyx * cyz_y + m_ezx * cyz_z;
+                    if (det33 != 0.0f) det33 = 1.0f / det33;
+                    det22 = m_exx * m_eyy - m_eyx * m_eyx;
+                    if (det22 != 0.0f) det22 = 1.0f / det22;
+                }
+            }
+            if (nRounds > 0) {
+                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                for (int r = 0; r < nRounds; ++r) {
+                    if (jround == r) {
+                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
+                        float wA = mbox[2][pl];
+                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
+                        float wB = mbox[2][lane];
+                        V2 P = mk(impX, impY);
+                        vA = vsub(vA, vscale(mA, P));
+                        wA -= iA * (vcross(rA, P) + motorImp + impZ);
+                        vB = vadd(vB, vscale(mB, P));
+                        wB += iB * (vcross(rB, P) + motorImp + impZ);
+                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
+                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
+                    }
+                }
+                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
+            }
+            // ---- velocity iterations ----
+            for (int it = 0; it < A.velIters; ++it) {
+                if (nRounds > 0) {
+                    mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                    for (int r = 0; r < nRounds; ++r) {
+                        if (jround == r) {
+                            V2 vA = mk(mbox[0][pl], mbox[1][pl]);
+                            float wA = mbox[2][pl];
+                            V2 vB = mk(mbox[0][lane], mbox[1][lane]);
+                            float wB = mbox[2][lane];
+                            // motor
+                            if (limitState != LIM_EQUAL) {
+                                float Cdot = wB - wA - motorSpeed;
+                                float impulse = -motorMass * Cdot;
+                                float oldImpulse = motorImp;
+                                motorImp = fclamp(oldImpulse + impulse, -maxMotorImpulse, maxMotorImpulse);
+                                impulse = motorImp - oldImpulse;
+                                wA -= iA * impulse;
+                                wB += iB * impulse;
+                            }
+                            if (limitState != LIM_INACTIVE) {
+                                V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
+                                float Cdot2 = wB - wA;
+                                // impulse = -m_mass.Solve33(Cdot)
+                                float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
+                                float sx = det33 * (bx * cyz_x + by * cyz_y + bz * cyz_z);
+                                // cross(b, ez)
+                                float cbx = by * m_ezz - bz * m_ezy, cby = bz * m_ezx - bx * m_ezz, cbz = bx * m_ezy - by * m_ezx;
+                                float sy = det33 * (m_exx * cbx + m_eyx * cby + m_ezx * cbz);
+                                // cross(ey, b)
+                                float ebx = m_eyy * bz - m_ezy * by, eby = m_ezy * bx - m_eyx * bz, ebz = m_eyx * by - m_eyy * bx;
+                                float sz = det33 * (m_exx * ebx + m_eyx * eby + m_ezx * ebz);
+                                float ix = -sx, iy = -sy, iz = -sz;
+                                if (limitState == LIM_EQUAL) {
+                                    impX += ix; impY += iy; impZ += iz;
+                                } else {
+                                    float newImpulse = impZ + iz;
+                                    bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
+                                    if (reduce) {
+                                        V2 rhs = vadd(vneg(Cdot1), vscale(impZ, mk(m_ezx, m_ezy)));
+                                        // m_mass.Solve22(rhs): a11=exx a12=eyx a21=exy(=eyx) a22=eyy
+                                        float rx = det22 * (m_eyy * rhs.x - m_eyx * rhs.y);
+                                        float ry = det22 * (m_exx * rhs.y - m_eyx * rhs.x);
+                                        ix = rx; iy = ry; iz = -impZ;
+                                        impX += rx; impY += ry; impZ = 0.0f;
+                                    } else {
+                                        impX += ix; impY += iy; impZ += iz;
+                                    }
+                                }
+                                V2 P = mk(ix, iy);
+                                vA = vsub(vA, vscale(mA, P));
+                                wA -= iA * (vcross(rA, P) + iz);
+                                vB = vadd(vB, vscale(mB, P));
+                                wB += iB * (vcross(rB, P) + iz);
+                            } else {
+                                V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
+                                V2 b = vneg(Cdot);
+                                V2 impulse = mk(det22 * (m_eyy * b.x - m_eyx * b.y), det22 * (m_exx * b.y - m_eyx * b.x));
+                                impX += impulse.x; impY += impulse.y;
+                                vA = vsub(vA, vscale(mA, impulse));
+                                wA -= iA * vcross(rA, impulse);
+                                vB = vadd(vB, vscale(mB, impulse));
+                                wB += iB * vcross(rB, impulse);
+                            }
+                            mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
+                            mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
+                        }
+                    }
+                    vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
+                }
+                // contacts of this body, in list order
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    if (t < nTouch) {
+                        ContactC &c = cc[t];
+                        V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
+                        V2 vB = mk(vx, vy);
+                        float wB = w;
+                        // friction first
+                        {
+                            V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
+                            float vt = vdot(dv, tangent) - 0.0f;
+                            float lambda = c.tm0 * (-vt);
+                            float maxFriction = friction * c.n0;
+                            float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
+                            lambda = newImpulse - c.t0;
+                            c.t0 = newImpulse;
+                            V2 P = vscale(lambda, tangent);
+                            vB = vadd(vB, vscale(mB, P));
+                            wB += iB * vcross(c.rB0, P);
+                        }
+                        if (c.count > 1) {
+                            V2 dv = vadd(vB, vcross_sv(wB, c.rB1));
+                            float vt = vdot(dv, tangent) - 0.0f;
+                            float lambda = c.tm1 * (-vt);
+                            float maxFriction = friction * c.n1;
+                            float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
+                            lambda = newImpulse - c.t1;
+                            c.t1 = newImpulse;
+                            V2 P = vscale(lambda, tangent);
+                            vB = vadd(vB, vscale(mB, P));
+                            wB += iB * vcross(c.rB1, P);
+                        }
+                        if (c.count == 1) {
+                            V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
+                            float vn = vdot(dv, normal);
+                            float lambda = -c.nm0 * (vn - 0.0f);
+                            float newImpulse = fmax32(c.n0 + lambda, 0.0f);
+                            lambda = newImpulse - c.n0;
+                            c.n0 = newImpulse;
+                            V2 P = vscale(lambda, normal);
+                            vB = vadd(vB, vscale(mB, P));
+                            wB += iB * vcross(c.rB0, P);
+                        } else {
+                            V2 a = mk(c.n0, c.n1);
+                            V2 dv1 = vadd(vB, vcross_sv(wB, c.rB0));
+                            V2 dv2 = vadd(vB, vcross_sv(wB, c.rB1));
+                            float vn1 = vdot(dv1, normal), vn2 = vdot(dv2, normal);
+                            V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
+                            b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
+                            V2 x;
+                            bool solved = false;
+                            // case 1
+                            x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y));
+                            solved = x.x >= 0.0f && x.y >= 0.0f;
+                            if (!solved) { // case 2
+                                x.x = -c.nm0 * b.x;
+                                x.y = 0.0f;
+                                vn2 = c.k12 * x.x + b.y;
+                                solved = x.x >= 0.0f && vn2 >= 0.0f;
+                            }
+                            if (!solved) { // case 3
+                                x.x = 0.0f;
+                                x.y = -c.nm1 * b.y;
+                                vn1 = c.k12 * x.y + b.x;
+                                solved = x.y >= 0.0f && vn1 >= 0.0f;
+                            }
+                            if (!solved) { // case 4
+                                x.x = 0.0f;
+                                x.y = 0.0f;
+                                solved = b.x >= 0.0f && b.y >= 0.0f;
+                            }
+                            if (solved) {
+                                V2 d = vsub(x, a);
+                                V2 P1 = vscale(d.x, normal), P2 = vscale(d.y, normal);
+                                vB = vadd(vB, vscale(mB, vadd(P1, P2)));
+                                wB += iB * (vcross(c.rB0, P1) + vcross(c.rB1, P2));
+                                c.n0 = x.x;
+                                c.n1 = x.y;
+                            }
+                        }
+                        vx = vB.x; vy = vB.y; w = wB;
+                    }
+                }
+            }
+            // ---- StoreImpulses ----
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                if (t < nTouch) {
+                    int ps = (slotPack >> (4 * t)) & 0xf;
+                    size_t o = (size_t)ps * Lp + gl;
+                    S.cN0[o] = cc[t].n0;
+                    S.cT0[o] = cc[t].t0;
+                    if (cc[t].count > 1) {
+                        S.cN1[o] = cc[t].n1;
+                        S.cT1[o] = cc[t].t1;
+                    }
+                }
+            }
+            // ---- integrate positions ----
+            if (active) {
+                V2 v = mk(vx, vy);
+                V2 translation = vscale(h, v);
+                if (vdot(translation, translation) > B2_MAX_TRANSLATION_SQ) {
+                    float ratio = B2_MAX_TRANSLATION / vlen(translation);
+                    v = vscale(ratio, v);
+                }
+                float rotation = h * w;
+                if (rotation * rotation > B2_MAX_ROTATION_SQ) {
+                    float ratio = B2_MAX_ROTATION / fabs32(rotation);
+                    w *= ratio;
+                }
+                px = px + h * v.x;
+                py = py + h * v.y;
+                ang += h * w;
+                vx = v.x; vy = v.y;
+            }
+            // ---- position iterations (per creature early exit) ----
+            bool envSolved = false;
+            int itersUsed = A.posIters;
+            for (int it = 0; it < A.posIters; ++it) {
+                float minSeparation = 0.0f;
+                if (!envSolved && active) {
+                    for (int t = 0; t < nTouch; ++t) {
+                        const float *sc = S.scr + (size_t)t * SCR_WORDS * Lp + gl;
+                        int tc = __float_as_int(sc[0]);
+                        int mtype = tc & 0xff, mcount = tc >> 8;
+                        V2 ln = mk(sc[1 * Lp], sc[2 * Lp]), lp = mk(sc[3 * Lp], sc[4 * Lp]);
+                        const float radiusA = B2_POLYGON_RADIUS;
+                        for (int j = 0; j < mcount; ++j) {
+                            V2 pj = mk(sc[(5 + 2 * j) * Lp], sc[(6 + 2 * j) * Lp]);
+                            V2 cB = mk(px, py);
+                            V2 normal, point;
+                            float separation;
+                            if (mtype == MF_CIRCLES) {
+                                Rot qB = rot_set(ang);
+                                V2 pointA = lp;
+                                V2 pointB = xmul(qB, cB, mk(sc[5 * Lp], sc[6 * Lp]));
+                                normal = vsub(pointB, pointA);
+                                vnormalize(normal);
+                                point = vscale(0.5f, vadd(pointA, pointB));
+                                separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
+                            } else if (mtype == MF_FACE_A) {
+                                Rot qB = rot_set(ang);
+                                normal = ln;
+                                V2 planePoint = lp;
+                                V2 clipPoint = xmul(qB, cB, pj);
+                                separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+                                point = clipPoint;
+                            } else {
+                                Rot qB = rot_set(ang);
+                                normal = rmul(qB, ln);
+                                V2 planePoint = xmul(qB, cB, lp);
+                                V2 clipPoint = pj;
+                                separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+                                point = clipPoint;
+                                normal = vneg(normal);
+                            }
+                            V2 rBp = vsub(point, cB);
+                            minSeparation = fmin32(minSeparation, separation);
+                            float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                            float rnB = vcross(rBp, normal);
+                            float Kn = mB + iB * rnB * rnB;
+                            float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+                            V2 P = vscale(impulse, normal);
+                            px = px + mB * P.x;
+                            py = py + mB * P.y;
+                            ang += iB * vcross(rBp, P);
+                        }
+                    }
+                }
+                int jointOk = 1;
+                if (nRounds > 0) {
+                    mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
+                    for (int r = 0; r < nRounds; ++r) {
+                        if (jround == r && !envSolved) {
+                            V2 cA = mk(mbox[0][pl], mbox[1][pl]);
+                            float aA = mbox[2][pl];
+                            V2 cB = mk(mbox[0][lane], mbox[1][lane]);
+                            float aB = mbox[2][lane];
+                            float angularError = 0.0f, positionError = 0.0f;
+                            if (limitState != LIM_INACTIVE) {
+                                float angle = aB - aA - 0.0f;
+                                float limitImpulse = 0.0f;
+                                if (limitState == LIM_EQUAL) {
+                                    float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
+                                    limitImpulse = -motorMass * C;
+                                    angularError = fabs32(C);
+                                } else if (limitState == LIM_AT_LOWER) {
+                                    float C = angle - jLower;
+                                    angularError = -C;
+                                    C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
+                                    limitImpulse = -motorMass * C;
+                                } else {
+                                    float C = angle - jUpper;
+                                    angularError = C;
+                                    C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
+                                    limitImpulse = -motorMass * C;
+                                }
+                                aA -= iA * limitImpulse;
+                                aB += iB * limitImpulse;
+                            }
+                            {
+                                Rot qA = rot_set(aA), qB = rot_set(aB);
+                                V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
+                                V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
+                                V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
+                                positionError = vlen(C);
+                                float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
+                                float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
+                                float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
+                                float det = Kexx * Keyy - Kexy * Kexy;
+                                if (det != 0.0f) det = 1.0f / det;
+                                V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
+                                V2 impulse = vneg(sol);
+                                cA = vsub(cA, vscale(mA, impulse));
+                                aA -= iA * vcross(prA, impulse);
+                                cB = vadd(cB, vscale(mB, impulse));
+                                aB += iB * vcross(prB, impulse);
+                            }
+                            mbox[0][pl] = cA.x; mbox[1][pl] = cA.y; mbox[2][pl] = aA;
+                            mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
+                            jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
+                        }
+                    }
+                    px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
+                }
+                float envMinSep = group_min<K>(minSeparation);
+                int envJointsOk = group_and<K>(jointOk);
+                bool okNow = (envMinSep >= -3.0f * B2_LINEAR_SLOP) && envJointsOk;
+                if (!envSolved && okNow) { envSolved = true; itersUsed = it + 1; }
+                if (__all(envSolved ? 1 : 0)) break;
+            }
+            lastPosIters = itersUsed;
+            // ---- write back / SynchronizeTransform happens lazily (q recomputed at the next use) ----
+            // ---- sleep ----
+            if (allowSleep) {
+                float myT = FLT_MAX;
+                if (active) {
+                    const float linTolSqr = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL;
+                    const float angTolSqr = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
+                    if (w * w > angTolSqr || vdot(mk(vx, vy), mk(vx, vy)) > linTolSqr) {
+                        sleepT = 0.0f;
+                        myT = 0.0f;
+                    } else {
+                        sleepT += h;
+                        myT = sleepT;
+                    }
+                }
+                float minSleepTime = group_min<K>(myT);
+                if (minSleepTime >= B2_TIME_TO_SLEEP && envSolved && active) {
+                    awake = 0; sleepT = 0.0f; vx = 0.0f; vy = 0.0f; w = 0.0f;
+                }
+            }
+            // ---- SynchronizeFixtures: swept AABB vs fat AABB (b2DynamicTree::MoveProxy) ----
+            if (active) {
+                Rot q0 = rot_set(a0);
+                Rot q1 = rot_set(ang);
+                V2 p0 = vsub(mk(c0x, c0y), rmul(q0, mk(0.0f, 0.0f)));
+                V2 p1 = vsub(mk(px, py), rmul(q1, mk(0.0f, 0.0f)));
+                AABB b1 = body_aabb(shape, hx, hy, p0, q0), b2 = body_aabb(shape, hx, hy, p1, q1);
+                V2 lo = vmin2(b1.lo, b2.lo), hi = vmax2(b1.hi, b2.hi);
+                V2 displacement = vsub(p1, p0);
+                bool contains = fatLo.x <= lo.x && fatLo.y <= lo.y && hi.x <= fatHi.x && hi.y <= fatHi.y;
+                if (!contains) {
+                    V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
+                    V2 flo = vsub(lo, r), fhi = vadd(hi, r);
+                    V2 d = vscale(B2_AABB_MULTIPLIER, displacement);
+                    if (d.x < 0.0f) flo.x += d.x; else fhi.x += d.x;
+                    if (d.y < 0.0f) flo.y += d.y; else fhi.y += d.y;
+                    fatLo = flo; fatHi = fhi;
+                    moved = true;
+                }
+            }
+            if (moved) find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err);
+        }
+        if (h > 0.0f) invDt0 = inv_dt;
+        // =============== reward / done / evaluate() fitness ===============
+        {
+            float rootx = __shfl(px, base);
+            double r = (double)rootx;
+            double rew = r;
+            int d = 0;
+            if (r < 0.0) { rew = -100.0; d = 1; }
+            if (wod > r) { rew = -100.0; d = 1; }
+            reward = (float)rew;
+            done = d;
+            everDone |= d;
+            if (!frozen) {
+                if (rew < -10.0) frozen = 1;
+                else if (rew > 100.0) { fitness = rew + (double)(10000 - stepIdx) / 10000.0; frozen = 1; }
+                else if (rew > 0.0) fitness = rew;
+            }
+            ++stepIdx;
+        }
+    }
+    // ---- store ----
+    S.px[gl] = px; S.py[gl] = py; S.ang[gl] = ang; S.vx[gl] = vx; S.vy[gl] = vy; S.w[gl] = w;
+    S.sleepT[gl] = sleepT; S.awake[gl] = awake;
+    S.fatLx[gl] = fatLo.x; S.fatLy[gl] = fatLo.y; S.fatUx[gl] = fatHi.x; S.fatUy[gl] = fatHi.y;
+    S.cCount[gl] = cCount;
+    S.jImpX[gl] = impX; S.jImpY[gl] = impY; S.jImpZ[gl] = impZ; S.jMotorImp[gl] = motorImp;
+    S.jLimit[gl] = limitState; S.jMotorSpeed[gl] = motorSpeed;
+    S.cIstate[gl] = cIstate;
+    int envErr = group_or<K>(err);
+    if (sub == 0) {
+        S.wod[env] = wod; S.fitness[env] = fitness; S.reward[env] = reward; S.done[env] = done;
+        S.everDone[env] = everDone; S.frozen[env] = frozen; S.steps[env] = stepIdx; S.invDt0[env] = invDt0;
+        S.newFix[env] = newFix; S.err[env] = S.err[env] | envErr; S.posIters[env] = lastPosIters;
+    }
+}
+
+// =====================================================================================
+// reset kernel: Modular2D.reset -> b2World() + create_robot
+// =====================================================================================
+DEV void box_mass(float hx, float hy, float &mass, float &I) { // b2PolygonShape::ComputeMass, density 1
+    const V2 vs[4] = {mk(-hx, -hy), mk(hx, -hy), mk(hx, hy), mk(-hx, hy)};
+    V2 center = mk(0.0f, 0.0f);
+    float area = 0.0f, In = 0.0f;
+    V2 s = mk(0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = vadd(s, vs[i]);
+    s = vscale(1.0f / 4.0f, s);
+    const float k_inv3 = 1.0f / 3.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V2 e1 = vsub(vs[i], s);
+        V2 e2 = vsub(vs[(i + 1) & 3], s);
+        float D = vcross(e1, e2);
+        float triangleArea = 0.5f * D;
+        area += triangleArea;
+        center = vadd(center, vscale(triangleArea * k_inv3, vadd(e1, e2)));
+        float ex1 = e1.x, ey1 = e1.y, ex2 = e2.x, ey2 = e2.y;
+        float intx2 = ex1 * ex1 + ex2 * ex1 + ex2 * ex2;
+        float inty2 = ey1 * ey1 + ey2 * ey1 + ey2 * ey2;
+        In += (0.25f * k_inv3 * D) * (intx2 + inty2);
+    }
+    const float density = 1.0f;
+    mass = density * area;
+    center = vscale(1.0f / area, center);
+    V2 mc = vadd(center, s);
+    float Iout = density * In;
+    Iout += mass * (vdot(mc, mc) - vdot(center, center));
+    // b2Body::ResetMassData with a single fixture
+    float m = 0.0f + mass;
+    V2 lc = vadd(mk(0.0f, 0.0f), vscale(mass, mc));
+    float Ib = 0.0f + Iout;
+    float invM = 1.0f / m;
+    lc = vscale(invM, lc);
+    Ib -= m * vdot(lc, lc);
+    mass = m;
+    I = Ib;
+}
+__global__ void rem2d_reset_kernel(State S, rem2d_morph M, int K) {
+    int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gl >= S.Lp) return;
+    int env = gl / K, sub = gl % K;
+    bool real = env < S.nEnvs;
+    int shape = real ? M.shape[gl] : 0;
+    float hx = real ? M.hx[gl] : 0.0f, hy = real ? M.hy[gl] : 0.0f;
+    float x = real ? M.x[gl] : 0.0f, y = real ? M.y[gl] : 0.0f, a = real ? M.angle[gl] : 0.0f;
+    float invM = 0.0f, invI = 0.0f;
+    if (shape == SHAPE_BOX) {
+        float m, I;
+        box_mass(hx, hy, m, I);
+        invM = 1.0f / m;
+        invI = I > 0.0f ? 1.0f / I : 0.0f;
+    } else if (shape == SHAPE_CIRCLE) {
+        const float density = 1.0f;
+        float mass = density * B2_PI * hx * hx;
+        float I = mass * (0.5f * hx * hx + vdot(mk(0.0f, 0.0f), mk(0.0f, 0.0f)));
+        float m = 0.0f + mass;
+        V2 lc = vadd(mk(0.0f, 0.0f), vscale(mass, mk(0.0f, 0.0f)));
+        float Ib = 0.0f + I;
+        invM = 1.0f / m;
+        lc = vscale(invM, lc);
+        Ib -= m * vdot(lc, lc);
+        invI = Ib > 0.0f ? 1.0f / Ib : 0.0f;
+    }
+    S.shape[gl] = shape;
+    S.hx[gl] = hx; S.hy[gl] = hy; S.invM[gl] = invM; S.invI[gl] = invI;
+    // b2Body ctor + ResetMassData: sweep.c = b2Mul(xf, localCenter = 0)
+    Rot q = rot_set(a);
+    V2 c = xmul(q, mk(x, y), mk(0.0f, 0.0f));
+    S.px[gl] = c.x; S.py[gl] = c.y; S.ang[gl] = a;
+    S.vx[gl] = 0.0f; S.vy[gl] = 0.0f; S.w[gl] = 0.0f; S.sleepT[gl] = 0.0f;
+    S.awake[gl] = shape != SHAPE_NONE ? 1 : 0;
+    // b2Fixture::CreateProxies: fat AABB of the initial transform
+    AABB bb = body_aabb(shape == SHAPE_NONE ? SHAPE_CIRCLE : shape, hx, hy, mk(x, y), q);
+    V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
+    V2 lo = vsub(bb.lo, r), hi = vadd(bb.hi, r);
+    S.fatLx[gl] = lo.x; S.fatLy[gl] = lo.y; S.fatUx[gl] = hi.x; S.fatUy[gl] = hi.y;
+    int parent = real && shape != SHAPE_NONE ? M.parent[gl] : -1;
+    S.parent[gl] = parent;
+    S.jround[gl] = real ? M.jround[gl] : 0;
+    S.jAx[gl] = real ? M.ax[gl] : 0.0f; S.jAy[gl] = real ? M.ay[gl] : 0.0f;
+    S.jBx[gl] = real ? M.bx[gl] : 0.0f; S.jBy[gl] = real ? M.by[gl] : 0.0f;
+    S.jTorque[gl] = real ? M.torque[gl] : 0.0f; S.jLower[gl] = real ? M.lower[gl] : 0.0f;
+    S.jUpper[gl] = real ? M.upper[gl] : 0.0f;
+    S.jImpX[gl] = 0.0f; S.jImpY[gl] = 0.0f; S.jImpZ[gl] = 0.0f; S.jMotorImp[gl] = 0.0f; S.jMotorSpeed[gl] = 0.0f;
+    S.jLimit[gl] = LIM_INACTIVE;
+    S.cAmp[gl] = real ? M.amp[gl] : 0.0; S.cPhase[gl] = real ? M.phase[gl] : 0.0; S.cFreq[gl] = real ? M.freq[gl] : 0.0;
+    S.cOffset[gl] = real ? M.offset[gl] : 0.0; S.cIstate[gl] = real ? M.istate[gl] : 0.0;
+    S.cCount[gl] = 0;
+    for (int s = 0; s < KC; ++s) {
+        size_t o = (size_t)s * S.Lp + gl;
+        S.cEdge[o] = -1; S.cInfo[o] = 0; S.cKey0[o] = 0u; S.cKey1[o] = 0u;
+        S.cN0[o] = 0.0f; S.cN1[o] = 0.0f; S.cT0[o] = 0.0f; S.cT1[o] = 0.0f;
+    }
+    if (sub == 0) {
+        S.wod[env] = 0.0; S.fitness[env] = 0.0; S.reward[env] = 0.0f; S.done[env] = 0; S.everDone[env] = 0;
+        S.frozen[env] = 0; S.steps[env] = 0; S.invDt0[env] = 0.0f; S.newFix[env] = 1; S.err[env] = 0;
+        S.posIters[env] = 0; S.toiEvents[env] = 0;
+    }
+}
+
+// =====================================================================================
+// host side: handle + C ABI
+// =====================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(REM2D_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct rem2d_world {
+    rem2d_world_cfg cfg;
+    Layout L;
+    char *state;
+    State S;
+    Terrain T;
+    float *terrainBuf;
+    bool haveTerrain, haveReset;
+    bool timing;
+    hipEvent_t ev0, ev1;
+    double accumMs;
+    int64_t launches;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
+extern "C" const char *rem2d_last_error(void) { return g_err.c_str(); }
+
+static bool cfg_ok(const rem2d_world_cfg *cfg) {
+    if (!cfg || cfg->n_envs <= 0) return false;
+    int k = cfg->lanes;
+    return k == 2 || k == 4 || k == 8 || k == 16 || k == 32;
+}
+extern "C" size_t rem2d_state_bytes(const rem2d_world_cfg *cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    return make_layout(cfg).total;
+}
+extern "C" int32_t rem2d_padded_envs(const rem2d_world_cfg *cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    return make_layout(cfg).Np;
+}
+
+static void bind_state(rem2d_world *w) {
+    State &S = w->S;
+    char *b = w->state;
+    const Layout &L = w->L;
+#define P(T, f) reinterpret_cast<T *>(b + L.off[f])
+    S.px = P(float, REM2D_F_PX); S.py = P(float, REM2D_F_PY); S.ang = P(float, REM2D_F_ANG);
+    S.vx = P(float, REM2D_F_VX); S.vy = P(float, REM2D_F_VY); S.w = P(float, REM2D_F_W);
+    S.sleepT = P(float, REM2D_F_SLEEPT); S.hx = P(float, REM2D_F_HX); S.hy = P(float, REM2D_F_HY);
+    S.invM = P(float, REM2D_F_INVM); S.invI = P(float, REM2D_F_INVI);
+    S.fatLx = P(float, REM2D_F_FATLX); S.fatLy = P(float, REM2D_F_FATLY);
+    S.fatUx = P(float, REM2D_F_FATUX); S.fatUy = P(float, REM2D_F_FATUY);
+    S.jAx = P(float, REM2D_F_JAX); S.jAy = P(float, REM2D_F_JAY); S.jBx = P(float, REM2D_F_JBX);
+    S.jBy = P(float, REM2D_F_JBY); S.jTorque = P(float, REM2D_F_JTORQUE); S.jLower = P(float, REM2D_F_JLOWER);
+    S.jUpper = P(float, REM2D_F_JUPPER); S.jImpX = P(float, REM2D_F_JIMPX); S.jImpY = P(float, REM2D_F_JIMPY);
+    S.jImpZ = P(float, REM2D_F_JIMPZ); S.jMotorImp = P(float, REM2D_F_JMOTORIMP);
+    S.jMotorSpeed = P(float, REM2D_F_JMOTORSPEED);
+    S.shape = P(int, REM2D_F_SHAPE); S.parent = P(int, REM2D_F_PARENT); S.jround = P(int, REM2D_F_JROUND);
+    S.awake = P(int, REM2D_F_AWAKE); S.jLimit = P(int, REM2D_F_JLIMIT); S.cCount = P(int, REM2D_F_CCOUNT);
+    S.cAmp = P(double, REM2D_F_CAMP); S.cPhase = P(double, REM2D_F_CPHASE); S.cFreq = P(double, REM2D_F_CFREQ);
+    S.cOffset = P(double, REM2D_F_COFFSET); S.cIstate = P(double, REM2D_F_CISTATE);
+    S.cEdge = P(int, REM2D_F_CEDGE); S.cInfo = P(int, REM2D_F_CINFO);
+    S.cKey0 = P(unsigned, REM2D_F_CKEY0); S.cKey1 = P(unsigned, REM2D_F_CKEY1);
+    S.cN0 = P(float, REM2D_F_CN0); S.cN1 = P(float, REM2D_F_CN1); S.cT0 = P(float, REM2D_F_CT0);
+    S.cT1 = P(float, REM2D_F_CT1);
+    S.wod = P(double, REM2D_F_WOD); S.fitness = P(double, REM2D_F_FITNESS); S.reward = P(float, REM2D_F_REWARD);
+    S.done = P(int, REM2D_F_DONE); S.everDone = P(int, REM2D_F_EVERDONE); S.frozen = P(int, REM2D_F_FROZEN);
+    S.steps = P(int, REM2D_F_STEPS); S.invDt0 = P(float, REM2D_F_INVDT0); S.newFix = P(int, REM2D_F_NEWFIX);
+    S.err = P(int, REM2D_F_ERR); S.posIters = P(int, REM2D_F_POSITERS); S.toiEvents = P(int, REM2D_F_TOIEVENTS);
+#undef P
+    S.Lp = L.Lp;
+    S.Np = L.Np;
+    S.nEnvs = w->cfg.n_envs;
+    S.flags = w->cfg.flags;
+}
+
+extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, size_t state_bytes, rem2d_world **out) {
+    if (!out) return fail(REM2D_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!cfg_ok(cfg)) return fail(REM2D_E_INVALID, "cfg: n_envs must be > 0 and lanes one of 2,4,8,16,32");
+    if (cfg->flags & REM2D_FLAG_CONTINUOUS)
+        return fail(REM2D_E_INVALID, "REM2D_FLAG_CONTINUOUS (SolveTOI) is not implemented on the HIP path yet");
+    Layout L = make_layout(cfg);
+    if (!state_dev || state_bytes < L.total) return fail(REM2D_E_INVALID, "state buffer missing or too small");
+    if (((uintptr_t)state_dev & 255) != 0) return fail(REM2D_E_INVALID, "state buffer must be 256-byte aligned");
+    HIP_TRY(hipSetDevice(cfg->device));
+    rem2d_world *w = new (std::nothrow) rem2d_world();
+    if (!w) return fail(REM2D_E_NOMEM, "host allocation failed");
+    w->cfg = *cfg;
+    w->L = L;
+    w->state = (char *)state_dev;
+    w->terrainBuf = nullptr;
+    w->haveTerrain = w->haveReset = false;
+    w->timing = false;
+    w->accumMs = 0.0;
+    w->launches = 0;
+    bind_state(w);
+    w->S.scr = nullptr;
+    hipError_t e = hipMalloc((void **)&w->S.scr, (size_t)KT * SCR_WORDS * L.Lp * sizeof(float));
+    if (e != hipSuccess) {
+        delete w;
+        return fail(REM2D_E_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    }
+    *out = w;
+    return REM2D_OK;
+}
+
+static void drain_timing(rem2d_world *w) {
+    for (auto &p : w->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            w->accumMs += ms;
+            w->launches += 1;
+        }
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    w->pending.clear();
+}
+
+extern "C" int rem2d_world_destroy(rem2d_world *w) {
+    if (!w) return REM2D_OK;
+    (void)hipSetDevice(w->cfg.device);
+    drain_timing(w);
+    if (w->S.scr) (void)hipFree(w->S.scr);
+    if (w->terrainBuf) (void)hipFree(w->terrainBuf);
+    delete w;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, int32_t npts, const float *polys,
+                                       int32_t npolys, float friction) {
+    if (!w || !xs || !ys || npts < 2) return fail(REM2D_E_INVALID, "terrain needs at least two polyline points");
+    if (npolys != 0 || polys != nullptr)
+        if (npolys != 0)
+            return fail(REM2D_E_INVALID, "hardcore static polygons are not implemented on the HIP path yet");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    int nEdge = npts - 1;
+    std::vector<float> h((size_t)8 * nEdge);
+    float *v1x = h.data(), *v1y = v1x + nEdge, *v2x = v1y + nEdge, *v2y = v2x + nEdge;
+    float *flx = v2y + nEdge, *fly = flx + nEdge, *fux = fly + nEdge, *fuy = fux + nEdge;
+    for (int i = 0; i < nEdge; ++i) {
+        // b2EdgeShape::ComputeAABB with the identity transform, then the broadphase fattening
+        float ax = (1.0f * xs[i] - 0.0f * ys[i]) + 0.0f, ay = (0.0f * xs[i] + 1.0f * ys[i]) + 0.0f;
+        float bx = (1.0f * xs[i + 1] - 0.0f * ys[i + 1]) + 0.0f, by = (0.0f * xs[i + 1] + 1.0f * ys[i + 1]) + 0.0f;
+        v1x[i] = xs[i]; v1y[i] = ys[i]; v2x[i] = xs[i + 1]; v2y[i] = ys[i + 1];
+        float lx = ax < bx ? ax : bx, ly = ay < by ? ay : by;
+        float ux = ax > bx ? ax : bx, uy = ay > by ? ay : by;
+        const float r = B2_POLYGON_RADIUS;
+        lx = lx - r; ly = ly - r; ux = ux + r; uy = uy + r;
+        flx[i] = lx - B2_AABB_EXTENSION; fly[i] = ly - B2_AABB_EXTENSION;
+        fux[i] = ux + B2_AABB_EXTENSION; fuy[i] = uy + B2_AABB_EXTENSION;
+    }
+    if (w->terrainBuf) { (void)hipFree(w->terrainBuf); w->terrainBuf = nullptr; }
+    HIP_TRY(hipMalloc((void **)&w->terrainBuf, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(w->terrainBuf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    Terrain &T = w->T;
+    T.nEdge = nEdge;
+    T.nPoly = 0;
+    T.v1x = w->terrainBuf; T.v1y = T.v1x + nEdge; T.v2x = T.v1y + nEdge; T.v2y = T.v2x + nEdge;
+    T.flx = T.v2y + nEdge; T.fly = T.flx + nEdge; T.fux = T.fly + nEdge; T.fuy = T.fux + nEdge;
+    T.x0 = xs[0];
+    float pitch = (xs[npts - 1] - xs[0]) / (float)nEdge;
+    if (!(pitch > 0.0f)) return fail(REM2D_E_INVALID, "terrain xs must be increasing");
+    // the edge scan assumes a (nearly) uniform pitch; verify so that the candidate range is conservative
+    for (int i = 0; i < npts; ++i) {
+        float expect = xs[0] + pitch * (float)i;
+        if (fabsf(xs[i] - expect) > 0.1f * pitch) return fail(REM2D_E_INVALID, "terrain xs must be uniformly spaced");
+    }
+    T.invPitch = 1.0f / pitch;
+    T.friction = sqrtf(friction * 0.1f); // b2MixFriction(terrain fixture, module fixture friction 0.1)
+    w->haveTerrain = true;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *stream) {
+    if (!w || !m) return fail(REM2D_E_INVALID, "world or morphology is NULL");
+    if (!m->shape || !m->hx || !m->hy || !m->x || !m->y || !m->angle || !m->parent || !m->jround || !m->ax || !m->ay ||
+        !m->bx || !m->by || !m->torque || !m->lower || !m->upper || !m->amp || !m->phase || !m->freq || !m->offset ||
+        !m->istate)
+        return fail(REM2D_E_INVALID, "morphology has NULL arrays");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    int threads = 256, blocks = (w->L.Lp + threads - 1) / threads;
+    hipLaunchKernelGGL(rem2d_reset_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, w->S, *m, w->cfg.lanes);
+    HIP_TRY(hipGetLastError());
+    w->haveReset = true;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
+                                   void *stream) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if (!w->haveTerrain) return fail(REM2D_E_STATE, "rem2d_world_set_terrain must be called before step");
+    if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
+    if (n_steps <= 0) return REM2D_OK;
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    StepArgs A;
+    A.nSteps = n_steps;
+    A.dt = dt;
+    A.velIters = vel_iters;
+    A.posIters = pos_iters;
+    dim3 grid(w->L.Lp / WAVE), block(WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (w->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    switch (w->cfg.lanes) {
+    case 2: hipLaunchKernelGGL(rem2d_step_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
+    case 4: hipLaunchKernelGGL(rem2d_step_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
+    case 8: hipLaunchKernelGGL(rem2d_step_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
+    case 16: hipLaunchKernelGGL(rem2d_step_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
+    default: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (w->timing) {
+        HIP_TRY(hipEventRecord(e1, st));
+        w->pending.emplace_back(e0, e1);
+    }
+    return REM2D_OK;
+}
+extern "C" int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream) {
+    // Modular2DEnv.py:634  self.world.Step(1.0/FPS, 6*30, 2*30)
+    return rem2d_world_step_ex(w, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream);
+}
+
+extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
+    if (!w || field < 0 || field >= REM2D_F_COUNT) return fail(REM2D_E_INVALID, "bad field id");
+    if (offset_bytes) *offset_bytes = w->L.off[field];
+    if (count) *count = w->L.count[field];
+    if (dtype) *dtype = kFields[field].dtype;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_world_enable_timing(rem2d_world *w, int32_t on) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    w->timing = on != 0;
+    return REM2D_OK;
+}
+extern "C" int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int64_t *launches) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    drain_timing(w);
+    if (total_ms) *total_ms = w->accumMs;
+    if (launches) *launches = w->launches;
+    w->accumMs = 0.0;
+    w->launches = 0;
+    return REM2D_OK;
+}

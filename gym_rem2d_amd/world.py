@@ -1,0 +1,117 @@
+"""BatchedWorld: N independent Box2D-style worlds stepped in lockstep on one MI355X.
+
+Thin host wrapper over the C ABI (include/rem2d.h).  Device memory is a single torch.uint8
+arena owned by this object; state fields are exposed as zero-copy torch views
+(``world.view("px")``).  PyTorch is used for memory, streams and (elsewhere)
+torch.distributed only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .compiler import MORPH_F32, MORPH_F64, MORPH_I32, Morphology
+from .terrain import TerrainProfile
+
+_DTYPES = {0: torch.float32, 1: torch.int32, 2: torch.float64}
+
+
+class BatchedWorld:
+    def __init__(self, n_envs, lanes, flags=0, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.Rem2dError("gym_rem2d_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.n_envs, self.lanes, self.flags = int(n_envs), int(lanes), int(flags)
+        L = _lib.lib()
+        self.cfg = _lib.WorldCfg(self.n_envs, self.lanes, self.flags, self.device.index or 0)
+        nbytes = L.rem2d_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise _lib.Rem2dError("invalid world shape: n_envs=%d lanes=%d" % (n_envs, lanes))
+        self.n_envs_padded = L.rem2d_padded_envs(C.byref(self.cfg))
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        _lib.check(L.rem2d_world_create(C.byref(self.cfg), self.arena.data_ptr(), nbytes, C.byref(h)))
+        self.h = h
+        self._views = {}
+        self._morph_dev = None
+        self.terrain = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().rem2d_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- terrain: _generate_terrain's static bodies, shared by every world ----
+    def set_terrain(self, terrain: TerrainProfile):
+        xs, ys, polys = terrain.f32()
+        xs, ys, polys = np.ascontiguousarray(xs), np.ascontiguousarray(ys), np.ascontiguousarray(polys)
+        _lib.check(_lib.lib().rem2d_world_set_terrain(
+            self.h, xs.ctypes.data, ys.ctypes.data, len(xs), polys.ctypes.data if len(polys) else None, len(polys),
+            float(terrain.friction)))
+        self.terrain = terrain
+
+    # ---- reset: upload the morphology and rebuild every world ----
+    def reset(self, morph: Morphology):
+        if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
+            raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %
+                             (morph.n_envs, morph.lanes, self.n_envs, self.lanes))
+        dev = {}
+        for k in MORPH_I32 + MORPH_F32 + MORPH_F64:
+            dev[k] = torch.from_numpy(morph.arrays[k]).to(self.device, non_blocking=False)
+        m = _lib.Morph()
+        for k in _lib.MORPH_FIELDS:
+            setattr(m, k, dev[k].data_ptr())
+        self._morph_dev = dev  # keep alive until the reset kernel has run
+        _lib.check(_lib.lib().rem2d_world_reset(self.h, C.byref(m), self._stream()))
+
+    def step(self, n_steps=1):
+        _lib.check(_lib.lib().rem2d_world_step(self.h, int(n_steps), self._stream()))
+
+    def step_ex(self, n_steps, dt, vel_iters, pos_iters):
+        _lib.check(_lib.lib().rem2d_world_step_ex(self.h, int(n_steps), float(dt), int(vel_iters), int(pos_iters),
+                                                  self._stream()))
+
+    # ---- zero-copy state views ----
+    def view(self, name):
+        v = self._views.get(name)
+        if v is None:
+            off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
+            _lib.check(_lib.lib().rem2d_world_field(self.h, _lib.FIELD_ID[name], C.byref(off), C.byref(cnt),
+                                                    C.byref(dt)))
+            dtype = _DTYPES[dt.value]
+            nb = cnt.value * (8 if dt.value == 2 else 4)
+            v = self.arena[off.value:off.value + nb].view(dtype)
+            Lp = self.n_envs_padded * self.lanes
+            if cnt.value == Lp:
+                v = v.view(self.n_envs_padded, self.lanes)[:self.n_envs]
+            elif cnt.value == Lp * _lib.CONTACT_SLOTS:
+                v = v.view(_lib.CONTACT_SLOTS, self.n_envs_padded, self.lanes)[:, :self.n_envs]
+            else:
+                v = v[:self.n_envs]
+            self._views[name] = v
+        return v
+
+    def bodies(self):
+        """[n_envs, lanes, 8] = x y angle vx vy w sleepTime awake (host numpy), as the oracle reports."""
+        torch.cuda.synchronize(self.device)
+        cols = [self.view(k).float() for k in ("px", "py", "ang", "vx", "vy", "w", "sleept")]
+        cols.append(self.view("awake").float())
+        return torch.stack(cols, dim=-1).cpu().numpy()
+
+    def enable_timing(self, on=True):
+        _lib.check(_lib.lib().rem2d_world_enable_timing(self.h, 1 if on else 0))
+
+    def kernel_time_ms(self):
+        t, n = C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().rem2d_world_kernel_time_ms(self.h, C.byref(t), C.byref(n)))
+        return t.value, n.value

@@ -1,0 +1,152 @@
+/*
+ * rem2d.h -- C ABI of the MI355X-native batched 2D rigid-body stepper (librem2d.so).
+ *
+ * Drop-in boundary for ONE path of FrankVeenstra/gym_rem2D: the world.Step() hot loop inside
+ * Modular2D.step()/reset().  In the reference that path crosses an FFI into pybox2d
+ * (Box2D==2.3.10, SWIG); each entry point below names the pybox2d calls / reference lines it
+ * replaces, batched over N independent worlds (one creature each).
+ *
+ * Conventions: plain C, no torch types.  Every function returns 0 on success or a negative
+ * REM2D_E_* code; rem2d_last_error() gives the text (thread-local).  Nothing throws across
+ * the boundary.  `state` is caller-owned device memory (e.g. one torch.uint8 tensor); the
+ * handle owns only its scratch.  One handle = one device = one stream at a time; distinct
+ * handles are independent.  No function synchronises the device except the *_read helpers.
+ *
+ * Data layout in HBM: structure of arrays, one 4- or 8-byte element per (creature, lane),
+ * lane fastest.  One lane = one rigid body (+ the revolute joint to its parent + the
+ * controller of the node that created it); `lanes` (2..32, power of two) consecutive lanes
+ * of one 64-wide wavefront form one creature, so a wave steps 64/lanes creatures in lockstep.
+ */
+#ifndef REM2D_H
+#define REM2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REM2D_ABI_VERSION 1
+
+enum {
+    REM2D_OK = 0,
+    REM2D_E_INVALID = -1, /* bad argument */
+    REM2D_E_HIP = -2,     /* HIP runtime error (text in rem2d_last_error) */
+    REM2D_E_STATE = -3,   /* call order (e.g. step before set_terrain / reset) */
+    REM2D_E_NOMEM = -4
+};
+
+/* flags */
+#define REM2D_FLAG_CONTINUOUS 1u         /* b2World continuousPhysics (SolveTOI) */
+#define REM2D_FLAG_SLEEP_RESET_ALWAYS 2u /* b2Body::SetAwake(true) always zeroes sleepTime */
+#define REM2D_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
+
+#define REM2D_MAX_LANES 32
+#define REM2D_CONTACT_SLOTS 8 /* broadphase pair slots per body */
+#define REM2D_SOLVER_SLOTS 6  /* touching contacts per body that enter the solver */
+
+typedef struct rem2d_world rem2d_world;
+
+typedef struct {
+    int32_t n_envs; /* creatures (independent b2Worlds) */
+    int32_t lanes;  /* lanes per creature: 2, 4, 8, 16 or 32 */
+    uint32_t flags; /* REM2D_FLAG_* */
+    int32_t device; /* HIP device ordinal */
+} rem2d_world_cfg;
+
+/* Morphology upload: DEVICE pointers to [n_envs*lanes] arrays (lane fastest).  Lane 0 of a
+ * creature is the root (no joint).  What each field replaces in the reference:
+ *   shape,hx,hy,x,y,angle : world.CreateDynamicBody(position, angle, fixtures=fixtureDef(
+ *                           polygonShape(box=(hx,hy)) | b2CircleShape(radius=hx), density=1,
+ *                           friction=0.1)) -- simple_module.py:286-298, circular_module.py:191-202
+ *   parent,ax..by,torque,lower,upper : world.CreateJoint(revoluteJointDef(bodyA, bodyB,
+ *                           localAnchorA, localAnchorB, enableMotor, enableLimit, maxMotorTorque,
+ *                           lowerAngle, upperAngle)) -- module_utility.py:19-32
+ *   jround                : parallel round of the joint that preserves b2World::Solve's island
+ *                           joint order (gym_rem2d_amd/compiler.py joint_rounds)
+ *   amp,phase,freq,offset,istate : node.controller -- Controller/m_controller.py:5-21 */
+typedef struct {
+    const int32_t *shape; /* 0 none, 1 box, 2 circle */
+    const float *hx, *hy, *x, *y, *angle;
+    const int32_t *parent; /* lane of the parent body inside the creature, -1 = none */
+    const int32_t *jround;
+    const float *ax, *ay, *bx, *by, *torque, *lower, *upper;
+    const double *amp, *phase, *freq, *offset, *istate;
+} rem2d_morph;
+
+/* State fields that can be viewed in place (rem2d_world_field).  Per-lane fields have
+ * n_envs_padded*lanes elements, per-creature fields n_envs_padded, contact fields
+ * REM2D_CONTACT_SLOTS * n_envs_padded*lanes (slot-major). */
+enum {
+    /* per lane, float */
+    REM2D_F_PX = 0, REM2D_F_PY, REM2D_F_ANG, REM2D_F_VX, REM2D_F_VY, REM2D_F_W, REM2D_F_SLEEPT,
+    REM2D_F_HX, REM2D_F_HY, REM2D_F_INVM, REM2D_F_INVI,
+    REM2D_F_FATLX, REM2D_F_FATLY, REM2D_F_FATUX, REM2D_F_FATUY,
+    REM2D_F_JAX, REM2D_F_JAY, REM2D_F_JBX, REM2D_F_JBY, REM2D_F_JTORQUE, REM2D_F_JLOWER, REM2D_F_JUPPER,
+    REM2D_F_JIMPX, REM2D_F_JIMPY, REM2D_F_JIMPZ, REM2D_F_JMOTORIMP, REM2D_F_JMOTORSPEED,
+    /* per lane, int32 */
+    REM2D_F_SHAPE, REM2D_F_PARENT, REM2D_F_JROUND, REM2D_F_AWAKE, REM2D_F_JLIMIT, REM2D_F_CCOUNT,
+    /* per lane, double */
+    REM2D_F_CAMP, REM2D_F_CPHASE, REM2D_F_CFREQ, REM2D_F_COFFSET, REM2D_F_CISTATE,
+    /* per contact slot x lane */
+    REM2D_F_CEDGE, REM2D_F_CINFO, REM2D_F_CKEY0, REM2D_F_CKEY1, REM2D_F_CN0, REM2D_F_CN1, REM2D_F_CT0,
+    REM2D_F_CT1,
+    /* per creature */
+    REM2D_F_WOD /* f64 */, REM2D_F_FITNESS /* f64 */, REM2D_F_REWARD /* f32 */, REM2D_F_DONE /* i32 */,
+    REM2D_F_EVERDONE /* i32 */, REM2D_F_FROZEN /* i32 */, REM2D_F_STEPS /* i32 */, REM2D_F_INVDT0 /* f32 */,
+    REM2D_F_NEWFIX /* i32 */, REM2D_F_ERR /* i32 */, REM2D_F_POSITERS /* i32 */, REM2D_F_TOIEVENTS /* i32 */,
+    REM2D_F_COUNT
+};
+enum { REM2D_DT_F32 = 0, REM2D_DT_I32 = 1, REM2D_DT_F64 = 2 };
+
+/* error bits in REM2D_F_ERR */
+#define REM2D_ERR_PAIR_OVERFLOW 1   /* more than REM2D_CONTACT_SLOTS fat-AABB pairs on a body */
+#define REM2D_ERR_SOLVER_OVERFLOW 2 /* more than REM2D_SOLVER_SLOTS touching contacts on a body */
+
+int rem2d_abi_version(void);
+const char *rem2d_last_error(void);
+
+/* Bytes of device memory the caller must provide for a world of this shape. */
+size_t rem2d_state_bytes(const rem2d_world_cfg *cfg);
+int32_t rem2d_padded_envs(const rem2d_world_cfg *cfg);
+
+/* Box2D.b2World() for n_envs worlds (Modular2DEnv.py:144,572): gravity (0,-10), sleeping,
+ * warm starting and continuous physics as pybox2d defaults (flags select variants). */
+int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, size_t state_bytes, rem2d_world **out);
+/* world teardown (Modular2DEnv.py:175-186 _destroy + garbage-collected b2World) */
+int rem2d_world_destroy(rem2d_world *w);
+
+/* _generate_terrain's world.CreateStaticBody(fixtures=fd_edge / fd_polygon) calls
+ * (Modular2DEnv.py:226-306): npts polyline points -> npts-1 edge bodies; polys [npolys][4][2]
+ * hardcore boxes in creation order.  HOST pointers (tiny, uploaded once, shared by all worlds). */
+int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, int32_t npts, const float *polys,
+                            int32_t npolys, float friction);
+
+/* Modular2D.reset (Modular2DEnv.py:565-598): destroy + re-create every world and build the
+ * robots (create_robot :517-563) from the uploaded layout; wall of death back to 0. */
+int rem2d_world_reset(rem2d_world *w, const rem2d_morph *morph_dev, void *stream);
+
+/* n_steps x Modular2D.step (Modular2DEnv.py:607-653): wod.update, controller sweep
+ * (m_controller.py:17-21), PID -> joint.motorSpeed (:600-605,:631-632),
+ * world.Step(1/50, 180, 60) (:634), reward / done (:642-649) and evaluate()'s fitness rule
+ * (REM2D_main.py:362-377).  Asynchronous on `stream` (hipStream_t). */
+int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream);
+/* same with explicit b2World::Step arguments (dt, velocityIterations, positionIterations) */
+int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
+                        void *stream);
+
+/* In-place view of a state field: byte offset into `state`, element count, REM2D_DT_*.
+ * Replaces the per-object reads body.position / body.angle / joint.angle and the per-step
+ * return values reward / done. */
+int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype);
+
+/* Average device time of the step kernel over the launches since the last call, measured
+ * with HIP events on the launch stream (bench.py's roofline leg).  Synchronises. */
+int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int64_t *launches);
+int rem2d_world_enable_timing(rem2d_world *w, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
