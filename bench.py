@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched stepper on N GPUs of one node.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run, one rank per GPU (RCCL).  One "step" = one Modular2D.step of every
+creature of the batch (controller + PID + world.Step(1/50, 180, 60) + reward/done).  Rank 0
+prints ONE JSON line.  Weak scaling: every rank steps its own 65 536 creatures; the only
+collective is one all-gather of fp32 fitness at the end of the timed region.
+
+Workloads (BASELINE.json configs), all synthetic:
+  lsystem  (default, the 65 536-creature config the metric is quoted on): random L-system
+           creatures, seeds 0..65535, maxModules=15, flat terrain; creatures are bucketed by
+           lane count (2/4/8/16) so that waves are homogeneous
+  chain8   65 536 identical 8-module chains (north_star's "8-module creatures")
+  chain4   4 096 identical 4-module chains (config 2)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def algorithmic_bytes(n_bodies):
+    """B(M, C) = 72 M + 100 (M-1) + 48 C + 12 bytes per env-step, C = 2 M."""
+    M = np.asarray(n_bodies, dtype=np.float64)
+    return 72 * M + 100 * np.maximum(M - 1, 0) + 48 * (2 * M) + 12
+
+
+def build_population(workload, n_envs, rank):
+    """Host-side synthetic input, built BEFORE the GPU is initialised (uses a fork pool)."""
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology, lanes_for
+    if workload == "chain4":
+        m = synthetic.chain_population(n_envs, 4, "left")
+        return [m], "%d identical 4-module chain creatures, flat terrain, sinusoidal controller" % n_envs
+    if workload == "chain8":
+        m = synthetic.chain_population(n_envs, 8, "left")
+        return [m], "%d identical 8-module chain creatures, flat terrain, sinusoidal controller" % n_envs
+    import multiprocessing as mp
+    seeds = np.arange(rank * n_envs, (rank + 1) * n_envs)
+    n_proc = max(1, min(8, os.cpu_count() or 1))
+    chunks = np.array_split(seeds, n_proc * 8)
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        parts = pool.map(synthetic.lsystem_specs, [c.tolist() for c in chunks])
+    specs = [s for p in parts for s in p]
+    groups = {}
+    for s in specs:
+        groups.setdefault(lanes_for(s.n_bodies), []).append(s)
+    morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
+    return morphs, ("%d random L-System creatures (seeds %d..%d, maxModules=15, <=16 bodies), flat terrain, "
+                    "bucketed by lane count %s" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
+
+
+def cpu_baseline(morphs, terrain, budget_s=12.0):
+    """The oracle (C restatement, OpenMP over creatures) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    O.build()
+    xs, ys, _ = terrain.f32()
+    ot = O.Terrain(xs, ys, None, terrain.friction)
+    cores = os.cpu_count() or 1
+    # sample: a proportional slice of every bucket, 64 creatures in total, 50 steps; repeat to fill the budget
+    total = sum(m.n_envs for m in morphs)
+    take = [max(1, int(round(64 * m.n_envs / total))) for m in morphs]
+    subs = [m.take(np.linspace(0, m.n_envs - 1, t).astype(np.int64)) for m, t in zip(morphs, take)]
+    steps, done_steps, t0 = 50, 0, time.time()
+    n = sum(s.n_envs for s in subs)
+    while True:
+        for s in subs:
+            O.batch_run(ot, s.as_dict(), steps, n_threads=cores)
+        done_steps += steps
+        if time.time() - t0 > budget_s or done_steps >= 2000:
+            break
+    dt = time.time() - t0
+    return {"value": n * done_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d creatures (proportional slice of every lane bucket) x %d steps from reset, "
+                      "oracle/rem2d_oracle.c with OpenMP over creatures" % (n, done_steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="lsystem", choices=["lsystem", "chain8", "chain4"])
+    ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (default: config size)")
+    ap.add_argument("--steps-per-launch", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_envs = args.envs or (4096 if args.workload == "chain4" else 65536)
+
+    morphs, workload_desc = build_population(args.workload, n_envs, rank)
+
+    import torch
+    import torch.distributed as dist
+    from gym_rem2d_amd import make_terrain
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import all_gather_fitness
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    env = BatchedModular2D(flat=True, seed=4, device=dev)
+    batches, lo = [], 0
+    for m in morphs:
+        batches.append((m, list(range(lo, lo + m.n_envs))))
+        lo += m.n_envs
+    env._upload(batches, lo)
+
+    spl = max(1, args.steps_per_launch)
+
+    def run(n):
+        left = n
+        while left > 0:
+            k = min(spl, left)
+            env.step(k)
+            left -= k
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(args.warmup)
+    for w, _ in env.worlds:
+        w.enable_timing(True)
+        w.kernel_time_ms()
+    sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fit = env.fitness.to(torch.float32)
+    if world > 1:
+        fit = all_gather_fitness(fit, n_envs * world)  # the generation's only collective
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel (the lane bucket with the most device time)
+    kern = []
+    for (w, _), m in zip(env.worlds, morphs):
+        ms, launches = w.kernel_time_ms()
+        w.enable_timing(False)
+        kern.append((ms, launches, m))
+    ms, launches, m = max(kern, key=lambda k: k[0])
+    bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
+    steps_per_launch_avg = args.steps / max(1, launches)
+    avg_ms = ms / max(1, launches)
+    achieved = bytes_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    err = int(env.errors().max())
+
+    if rank == 0:
+        out = {
+            "metric": "env steps/sec (whole node) at 65 536 parallel creatures",
+            "value": n_envs * world * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload_desc, "envs_per_gpu": n_envs, "steps_per_launch": spl,
+                       "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,
+                       "parallelism": "population sharded over %d GPU(s), no per-step collective" % world,
+                       "solver_errors": err},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "rem2d_step_kernel<%d>" % m.lanes, "avg_launch_ms": avg_ms,
+                         "launches": launches,
+                         "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d); "
+                                 "the path is FP32-VALU/latency bound, not HBM bound"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from gym_rem2d_amd import make_terrain as _mt
+            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=True))
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -538,7 +538,8 @@ DEV void pairs_remove(const State &S, int gl, int &count, int s) {
     S.cEdge[(size_t)count * S.Lp + gl] = -1;
 }
 // b2BroadPhase::UpdatePairs for one moved body proxy: new pairs in ascending edge (= proxy id) order
-DEV void find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2 flo, V2 fhi, int &err) {
+DEV bool find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2 flo, V2 fhi, int &err) {
+    bool added = false;
     int lo = (int)floorf((flo.x - 0.25f - T.x0) * T.invPitch) - 1;
     int hi = (int)floorf((fhi.x + 0.25f - T.x0) * T.invPitch) + 1;
     lo = lo < 0 ? 0 : lo;
@@ -547,8 +548,12 @@ DEV void find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2
         if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), flo, fhi)) continue;
         bool exists = false;
         for (int s = 0; s < count; ++s) exists |= (S.cEdge[(size_t)s * S.Lp + gl] == e);
-        if (!exists) pairs_insert_front(S, gl, count, e, err);
+        if (!exists) {
+            pairs_insert_front(S, gl, count, e, err);
+            added = true; // b2ContactManager::AddPair wakes both bodies
+        }
     }
+    return added;
 }
 
 // =====================================================================================
@@ -630,7 +635,10 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
         // =============== b2World::Step ===============
         const float dtRatio = invDt0 * h;
         if (newFix) { // FindNewContacts for freshly created fixtures
-            if (active) find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err);
+            if (active && find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err)) {
+                if (sleepResetAlways || !awake) sleepT = 0.0f;
+                awake = 1;
+            }
             newFix = 0;
         }
         Rot q = rot_set(ang); // body transform m_xf (q from sweep.a, p = c since localCenter = 0)
@@ -643,6 +651,8 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 size_t o = (size_t)s * Lp + gl;
                 int e = S.cEdge[o];
                 if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), fatLo, fatHi)) {
+                    // b2ContactManager::Destroy wakes the bodies of a touching contact
+                    if ((S.cInfo[o] & 0xff) > 0 && sleepResetAlways) sleepT = 0.0f;
                     pairs_remove(S, gl, cCount, s);
                     continue;
                 }
@@ -652,6 +662,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 else collide_edge_circle(m, e1, e2, hx, mk(px, py));
                 // b2Contact::Update: carry impulses over by feature id
                 int oldCount = S.cInfo[o] & 0xff;
+                if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed
                 unsigned ok0 = S.cKey0[o], ok1 = S.cKey1[o];
                 float on0 = S.cN0[o], on1 = S.cN1[o], ot0 = S.cT0[o], ot1 = S.cT1[o];
                 float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
         float c0x = px, c0y = py, a0 = ang;
         bool moved = false;
         if (envAwake) {
-            if (active && !awake) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
+            if (active && (!awake || sleepResetAlways)) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
             // ---- integrate velocities (gravity (0,-10), no forces, no damping) ----
             if (active) {
                 V2 acc = vadd(vscale(1.0f, mk(0.0f, -10.0f)), vscale(mB, mk(0.0f, 0.0f)));
@@ -1227,7 +1238,10 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                     moved = true;
                 }
             }
-            if (moved) find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err);
+            if (moved && find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err)) {
+                if (sleepResetAlways || !awake) sleepT = 0.0f; // AddPair -> SetAwake(true)
+                awake = 1;
+            }
         }
         if (h > 0.0f) invDt0 = inv_dt;
         // =============== reward / done / evaluate() fitness ===============

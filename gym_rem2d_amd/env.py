@@ -1,0 +1,246 @@
+"""gym-shaped environments on top of the batched MI355X stepper.
+
+``Modular2D`` keeps the reference env's surface (``gym_rem2D/envs/Modular2DEnv.py:127-173,
+565-653``): ``seed(int) -> [seed]``, ``reset(tree=, module_list=) -> None``,
+``step(action) -> (0, reward, done, 0)``, attributes ``action_space``, ``observation_space``,
+``hardcore``, ``robot.components/joints``, ``tree_morphology``, ``wod``.  It is a batch of one.
+
+``BatchedModular2D`` is the same environment for N creatures at once: ``reset(trees,
+module_lists)`` compiles every tree into the SoA layout, groups creatures by lane count
+(homogeneous waves) and uploads them; ``step(n)`` advances all of them n steps on the GPU and
+returns ``reward[N]`` / ``done[N]`` torch tensors.  Rendering (pyglet, ``:655-768``) is out of
+scope.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import gymshim
+from .compiler import Morphology, build_creature, lanes_for
+from .terrain import make_terrain
+from .world import BatchedWorld
+
+FPS = 50
+WOD_SPEED = 0.04
+VIEWPORT_W, VIEWPORT_H, SCALE = 800, 600, 30.0
+
+
+class ModularRobotBox2D:
+    """robot.components / robot.joints containers (Modular2DEnv.py:69-82)."""
+
+    def __init__(self):
+        self.components, self.joints = [], []
+
+    def add_components(self, components, joints=None):
+        self.components.extend(components)
+        if joints is not None:
+            self.joints.extend(joints)
+        return self
+
+
+class WallOfDeath:
+    def __init__(self, speed):
+        self.position = 0.0
+        self.speed = speed
+
+    def update(self):
+        self.position += self.speed
+
+
+class BatchedModular2D:
+    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=0):
+        self.hardcore, self.flat, self.flags = hardcore, flat, flags
+        self.device = device
+        self._seed = seed
+        self.terrain = None
+        self.worlds = []      # list of (BatchedWorld, env index tensor)
+        self.n_envs = 0
+        self.trees = None
+        self.robots = None
+        self._reward = self._done = None
+
+    def seed(self, seed=None):
+        self._seed = seed
+        self.terrain = None
+        return [seed]
+
+    def _terrain(self):
+        if self.terrain is None:
+            self.terrain = make_terrain(self._seed, hardcore=self.hardcore, flat=self.flat)
+        return self.terrain
+
+    # ---- reset from phenotype trees (reference-shaped) ----
+    def reset(self, trees, module_lists=None):
+        """trees: list of Tree; module_lists: list (or one shared list) of module prototypes.
+        Like the reference, each tree is deep-copied so that the env owns controller state."""
+        if module_lists is None or (len(module_lists) > 0 and not isinstance(module_lists[0], (list, tuple))):
+            module_lists = [module_lists] * len(trees)
+        self.trees, self.robots, specs = [], [], []
+        for tree, ml in zip(trees, module_lists):
+            t = copy.deepcopy(tree)
+            spec, comps, joints = build_creature(t.getNodes(), ml)
+            self.trees.append(t)
+            self.robots.append(ModularRobotBox2D().add_components(comps, joints))
+            specs.append(spec)
+        self.reset_specs(specs)
+        self._bind_views()
+
+    def reset_specs(self, specs):
+        groups = {}
+        for e, s in enumerate(specs):
+            groups.setdefault(lanes_for(s.n_bodies), []).append(e)
+        batches = []
+        for lanes in sorted(groups):
+            idx = groups[lanes]
+            batches.append((Morphology.from_specs([specs[e] for e in idx], lanes), idx))
+        self._upload(batches, len(specs))
+
+    def reset_morphology(self, morph):
+        """Fast path: a precompiled SoA batch (one lane count)."""
+        self.trees = self.robots = None
+        self._upload([(morph, list(range(morph.n_envs)))], morph.n_envs)
+
+    def _upload(self, batches, n_envs):
+        for w, _ in self.worlds:
+            w.close()
+        self.worlds = []
+        self.n_envs = n_envs
+        self.streams = []
+        for morph, idx in batches:
+            w = BatchedWorld(morph.n_envs, morph.lanes, self.flags, self.device)
+            w.set_terrain(self._terrain())
+            w.reset(morph)
+            self.worlds.append((w, torch.as_tensor(idx, dtype=torch.long, device=w.device)))
+            # one HIP stream per lane-count bucket so that the buckets' kernels overlap on the chip
+            self.streams.append(torch.cuda.Stream(device=w.device) if len(batches) > 1 else None)
+        dev = self.worlds[0][0].device
+        self._reward = torch.zeros(n_envs, dtype=torch.float32, device=dev)
+        self._done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
+        self._fitness = torch.zeros(n_envs, dtype=torch.float64, device=dev)
+
+    def _bind_views(self):
+        """Let node.component / robot.components read live poses (host read-back; API parity only)."""
+        if self.robots is None:
+            return
+        where = {}
+        for w, idx in self.worlds:
+            for local, e in enumerate(idx.tolist()):
+                where[e] = (w, local)
+        for e, robot in enumerate(self.robots):
+            w, local = where[e]
+
+            def live(slot, w=w, local=local):
+                return (float(w.view("px")[local, slot]), float(w.view("py")[local, slot]),
+                        float(w.view("ang")[local, slot]))
+            for b in robot.components:
+                b._live = live
+
+    # ---- step ----
+    def step(self, n_steps=1):
+        if len(self.worlds) == 1:
+            self.worlds[0][0].step(n_steps)
+        else:
+            cur = torch.cuda.current_stream(self.worlds[0][0].device)
+            for (w, _), st in zip(self.worlds, self.streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    w.step(n_steps)
+            for st in self.streams:
+                cur.wait_stream(st)
+        if len(self.worlds) == 1:
+            w = self.worlds[0][0]
+            return w.view("reward"), w.view("done") != 0
+        for w, idx in self.worlds:
+            self._reward.index_copy_(0, idx, w.view("reward"))
+            self._done.index_copy_(0, idx, w.view("done") != 0)
+        return self._reward, self._done
+
+    def _gather(self, name, out):
+        if len(self.worlds) == 1:
+            return self.worlds[0][0].view(name)
+        for w, idx in self.worlds:
+            out.index_copy_(0, idx, w.view(name).to(out.dtype))
+        return out
+
+    @property
+    def fitness(self):
+        """evaluate()'s running fitness (REM2D_main.py:362-377), float64 [N]."""
+        return self._gather("fitness", self._fitness)
+
+    @property
+    def frozen(self):
+        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
+        return self._gather("frozen", out)
+
+    def errors(self):
+        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
+        return self._gather("err", out)
+
+    def close(self):
+        for w, _ in self.worlds:
+            w.close()
+        self.worlds = []
+
+
+class Modular2D(gymshim.Env):
+    """Single-creature facade with the reference's call signatures."""
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': FPS}
+    hardcore = False
+
+    def __init__(self, random_seed=None, device=None):
+        self._device = device
+        self.seed(random_seed)
+        self.viewer = None
+        self.tree_morphology = None
+        self.robot = None
+        self.world = None
+        self.wod = None
+        self.game_over = False
+        high = np.array([np.inf] * 24)
+        self.action_space = gymshim.Box(np.array([-1, -1, -1, -1]), np.array([1, 1, 1, 1]), dtype=np.float32)
+        self.observation_space = gymshim.Box(-high, high, dtype=np.float32)
+        self._batch = None
+
+    def seed(self, seed=None):
+        self.np_random, seed = gymshim.np_random(seed)
+        self._seed_value = seed
+        return [seed]
+
+    def reset(self, tree=None, module_list=None):
+        self.wod = WallOfDeath(WOD_SPEED)
+        self.game_over = False
+        if self._batch is not None:
+            self._batch.close()
+        self._batch = None
+        self.tree_morphology = None
+        self.robot = ModularRobotBox2D()
+        if tree is None:
+            return
+        self._batch = BatchedModular2D(hardcore=self.hardcore, seed=self._seed_value, device=self._device)
+        self._batch.reset([tree], [module_list])
+        self.tree_morphology = self._batch.trees[0]
+        self.robot = self._batch.robots[0]
+        self.world = self._batch.worlds[0][0]
+        return
+
+    def step(self, action):
+        if self.wod:
+            self.wod.update()
+        if self.tree_morphology is None:
+            raise Exception("no tree_morphology")
+        n_ctrl = sum(1 for n in self.tree_morphology.nodes
+                     if n.controller is not None and n.expressed and n.component is not None)
+        assert n_ctrl - 1 == len(self.robot.joints)
+        reward, done = self._batch.step(1)
+        r = float(reward[0])
+        d = bool(done[0])
+        return 0, (r if not d else -100), (True if d else 0), 0
+
+    def render(self, mode='human'):
+        raise NotImplementedError("rendering is outside the accelerated path (SURVEY.md section 2)")
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None

@@ -1,0 +1,111 @@
+"""Episode loop and population evaluation.
+
+``evaluate`` has the reference's signature and fitness rule (``REM2D_main.py:350-378`` ==
+``Demo1_Random_Individual.py:4-36``).  ``evaluate_population`` replaces
+``pool.map(evaluate, population)`` (``REM2D_main.py:256-267,291``) with one batched episode on
+the GPU; ``evaluate_population_sharded`` shards the population over the ranks of a
+torch.distributed job (one process per GPU, contiguous blocks) and gathers the fitness with a
+single all-gather -- RCCL over xGMI on the MI355X node, gloo in the CPU tests.  There is no
+per-step collective: creatures are independent.
+"""
+import math
+
+import numpy as np
+import torch
+
+EPISODE_CAP = 2500  # wall of death advances 0.04/step and the goal is x > 100
+
+
+def _env_singleton():
+    global _ENV
+    try:
+        return _ENV
+    except NameError:
+        from .env import Modular2D
+        _ENV = Modular2D()
+        return _ENV
+
+
+def evaluate(individual, EVALUATION_STEPS=10000, HEADLESS=True, INTERVAL=100, ENV_LENGTH=100, TREE_DEPTH=None,
+             CONTROLLER=None):
+    """One individual, one episode, reference semantics (action ignored, reward sentinels)."""
+    env = _env_singleton()
+    if TREE_DEPTH is None:
+        try:
+            TREE_DEPTH = individual.tree_depth
+        except AttributeError:
+            raise Exception("Tree depth not defined in evaluation")
+    tree = individual.genome.create(TREE_DEPTH)
+    env.seed(4)
+    env.reset(tree=tree, module_list=individual.genome.moduleList)
+    fitness = 0
+    for i in range(EVALUATION_STEPS):
+        action = np.ones_like(env.action_space.sample())
+        _, reward, done, _ = env.step(action)
+        if reward < -10:
+            break
+        elif reward > ENV_LENGTH:
+            reward += (EVALUATION_STEPS - i) / EVALUATION_STEPS
+            fitness = reward
+            break
+        if reward > 0:
+            fitness = reward
+    return fitness
+
+
+def run_episode(env, max_steps=EPISODE_CAP, chunk=100):
+    """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
+    Returns fitness[N] (float64 tensor on the env's device)."""
+    done_steps = 0
+    while done_steps < max_steps:
+        n = min(chunk, max_steps - done_steps)
+        env.step(n)
+        done_steps += n
+        if bool((env.frozen != 0).all()):
+            break
+    return env.fitness.clone()
+
+
+def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, **env_kw):
+    """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats."""
+    from .env import BatchedModular2D
+    own = env is None
+    if own:
+        env = BatchedModular2D(**env_kw)
+    trees = [ind.genome.create(tree_depth if tree_depth is not None else ind.tree_depth) for ind in individuals]
+    env.reset(trees, [ind.genome.moduleList for ind in individuals])
+    fit = run_episode(env, max_steps).cpu().tolist()
+    if own:
+        env.close()
+    return fit
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank` (rank r owns [r*ceil(n/W), (r+1)*ceil(n/W)))."""
+    per = math.ceil(n / world_size)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def all_gather_fitness(local, n_total, group=None):
+    """One all_gather of fp32 fitness scalars: [per] -> [n_total] on every rank.  `local` is
+    padded to ceil(n/W) so that the collective is a single equal-sized all_gather_into_tensor."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = math.ceil(n_total / world)
+    buf = torch.zeros(per, dtype=torch.float32, device=local.device)
+    buf[:local.numel()] = local.to(torch.float32)
+    out = torch.empty(per * world, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out[:n_total]
+
+
+def evaluate_population_sharded(n_total, local_eval, group=None, device=None):
+    """Shard [0, n_total) over the job's ranks, evaluate the local block with
+    ``local_eval(lo, hi) -> tensor[hi-lo]`` and all-gather.  Returns fitness[n_total] (fp32)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_total, rank, world)
+    local = local_eval(lo, hi)
+    local = torch.as_tensor(local, dtype=torch.float32, device=device if device is not None else None)
+    return all_gather_fitness(local, n_total, group)

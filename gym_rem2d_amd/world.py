@@ -102,7 +102,7 @@ class BatchedWorld:
         return v
 
     def bodies(self):
-        """[n_envs, lanes, 8] = x y angle vx vy w sleepTime awake (host numpy), as the oracle reports."""
+        """[n_envs, lanes, 8] = x y angle vx vy w sleepTime awake (host numpy)."""
         torch.cuda.synchronize(self.device)
         cols = [self.view(k).float() for k in ("px", "py", "ang", "vx", "vy", "w", "sleept")]
         cols.append(self.view("awake").float())

@@ -1,0 +1,68 @@
+"""C-ABI library: builds for gfx950, loads, exports every symbol include/rem2d.h declares, and its
+host-only entry points behave (no compute calls: there is no GPU in the CPU test tier)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from gym_rem2d_amd import _lib
+    return _lib
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "rem2d.h")).read()
+    names = sorted(set(re.findall(r"\b(rem2d_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    L = C.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "librem2d.so does not export %s" % n
+
+
+def test_field_table_matches_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "rem2d.h")).read()
+    body = hdr[hdr.index("REM2D_F_PX = 0"):hdr.index("REM2D_F_COUNT")]
+    ids = re.findall(r"\bREM2D_F_([A-Z0-9]+)\b", body)
+    assert [i.lower() for i in ids] == lib.FIELDS
+
+
+def test_host_only_entry_points(lib):
+    L = lib.lib()
+    assert L.rem2d_abi_version() == 1
+    cfg = lib.WorldCfg(65536, 8, 0, 0)
+    n = L.rem2d_state_bytes(C.byref(cfg))
+    # every field is per lane / per slot / per creature: a few hundred bytes per body
+    assert 400 * 65536 * 8 < n < 800 * 65536 * 8
+    assert L.rem2d_padded_envs(C.byref(cfg)) == 65536
+    assert L.rem2d_padded_envs(C.byref(lib.WorldCfg(5, 4, 0, 0))) == 16
+    assert L.rem2d_state_bytes(C.byref(lib.WorldCfg(10, 3, 0, 0))) == 0  # lanes must be a power of two
+    h = C.c_void_p()
+    rc = L.rem2d_world_create(C.byref(lib.WorldCfg(10, 3, 0, 0)), None, 0, C.byref(h))
+    assert rc == -1 and b"lanes" in L.rem2d_last_error()
+    assert L.rem2d_world_destroy(None) == 0
+    assert L.rem2d_world_step(None, 1, None) == -1
+
+
+def test_product_never_imports_oracle():
+    """The product path must not import, link, load or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "gym_rem2d_amd")
+    bad = re.compile(r"(^\s*(import|from)\s+oracle\b)|librem2d_oracle|oracle[/\\]|rem2d_oracle", re.M)
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not bad.search(src), "%s reaches into the oracle" % f
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/librem2d.so")
+    with pytest.raises(lib.Rem2dError):
+        lib.lib()

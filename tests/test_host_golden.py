@@ -1,0 +1,158 @@
+"""Host layer vs golden vectors captured from the reference's importable Python side
+(tools/capture_golden.py -> tests/golden/*.json): terrain profile, encodings, create_robot
+layout, joint anchors, controller/PID sequence.  Everything here is bit-exact."""
+import copy
+import json
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import oracle_terrain
+from gym_rem2d_amd import Morphology, build_creature, get_module_list, make_terrain, synthetic
+from gym_rem2d_amd.compiler import f32
+from gym_rem2d_amd.encodings import DirectEncoding, LSystem
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name,kw", [("default", {}), ("flat", {"flat": True}), ("hardcore", {"hardcore": True})])
+def test_terrain_profile(name, kw):
+    g = load("terrain_seed4.json")[name]
+    t = make_terrain(4, **kw)
+    assert np.array_equal(t.xs, np.array(g["x"]))
+    assert np.array_equal(t.ys, np.array(g["y"]))
+    assert np.array_equal(t.polys, np.array(g["polys"], dtype=np.float64).reshape(-1, 4, 2))
+    assert g["n_edges"] == 199 and t.friction == g["friction"]
+    if name == "flat":
+        assert np.all(t.ys == 5.0)
+
+
+def _genome(enc, seed):
+    random.seed(seed)
+    ml = get_module_list()
+    g = DirectEncoding(ml) if enc == "direct" else LSystem(ml)
+    if enc == "lsystem" and seed % 2 == 1:
+        for _ in range(3):
+            g.mutate(0.5, 0.5, 0.5)
+    return g, ml
+
+
+def _check_tree(nodes, gt):
+    assert len(nodes) == len(gt)
+    for n, gn in zip(nodes, gt):
+        con = None if n.parent_connection_coordinates is None else n.parent_connection_coordinates.name
+        assert (n.index, n.parent, n.type, con) == (gn["index"], gn["parent"], gn["type"], gn["con"])
+        m, gm = n.module_, gn["module"]
+        assert m.type == gm["type"] and m.angle == gm["angle"] and m.torque == gm["torque"]
+        if m.type == "SIMPLE":
+            assert (m.width, m.height) == (gm["width"], gm["height"])
+        else:
+            assert m.radius == gm["radius"]
+        c, gc = n.controller, gn["controller"]
+        assert (c.amplitude, c.phase, c.frequency, c.offset) == (gc["amplitude"], gc["phase"], gc["frequency"], gc["offset"])
+
+
+def _check_layout(spec, nodes, L):
+    assert len(spec.bodies) == len(L["bodies"]) and len(spec.joints) == len(L["joints"])
+    for b, gb in zip(spec.bodies, L["bodies"]):
+        if gb["kind"] == "polygon":
+            assert b.shape == 1 and [b.hx, b.hy] == gb["box"]
+        else:
+            assert b.shape == 2 and b.hx == gb["radius"]
+        assert (b._x, b._y, b._angle) == (gb["x"], gb["y"], gb["angle"])
+        assert gb["friction"] == 0.1 and gb["categoryBits"] == 0x20 and gb["maskBits"] == 0x1
+    for j, gj in zip(spec.joints, L["joints"]):
+        assert (j["parent"], j["child"]) == (gj["bodyA"], gj["bodyB"])
+        assert [j["ax"], j["ay"]] == gj["anchorA"] and [j["bx"], j["by"]] == gj["anchorB"]
+        assert (j["torque"], j["lower"], j["upper"]) == (gj["torque"], gj["lower"], gj["upper"])
+        assert gj["enableMotor"] and gj["enableLimit"] and gj["referenceAngle"] == 0.0
+        assert gj["bodyB"] == L["joints"].index(gj) + 1  # joint k <-> body k+1
+    for n, fl, slot in zip(nodes, L["node_flags"], spec.node_slots):
+        assert bool(n.expressed) == fl["expressed"] and (n.component is not None) == fl["has_component"]
+        assert slot == fl["body"]
+
+
+def _check_control(spec, nodes, L):
+    """Controller sweep + PID with the bodies frozen at their construction pose
+    (Modular2DEnv.py:613-632), python doubles -> float32 motorSpeed."""
+    ctrls = [n.controller for n in nodes if n.controller is not None and n.expressed and n.component is not None]
+    angles = [f32(np.float32(spec.bodies[j["child"]]._angle) - np.float32(spec.bodies[j["parent"]]._angle))
+              for j in spec.joints]
+    wod = 0.0
+    for k, rec in enumerate(L["control"]):
+        wod += 0.04
+        cv = [c.update(0) for c in ctrls]
+        ms = [f32((cv[i + 1] - angles[i]) * 1.9) for i in range(len(spec.joints))]
+        assert ms == rec["motorSpeed"]
+        assert rec["wod"] == wod
+        assert rec["reward"] == (5.0 if wod <= 5.0 else -100)
+
+
+@pytest.mark.parametrize("enc", ["direct", "lsystem"])
+def test_encoding_and_layout(enc):
+    G = load("layout_%s.json" % enc)
+    assert len(G["cases"]) == 40
+    for case in G["cases"]:
+        genome, ml = _genome(enc, case["seed"])
+        tree = genome.create(8)
+        _check_tree(tree.getNodes(), case["tree"])
+        t2 = copy.deepcopy(tree)
+        nodes = t2.getNodes()
+        spec, comps, joints = build_creature(nodes, ml)
+        _check_layout(spec, nodes, case["layout"])
+        assert len(comps) == spec.n_bodies and len(joints) == len(spec.joints)
+        _check_control(spec, nodes, case["layout"])
+
+
+@pytest.mark.parametrize("site", ["top", "left", "right"])
+def test_chain_layout(site):
+    G = load("layout_chain.json")[site]
+    tree = synthetic.chain_tree(4, site)
+    _check_tree(tree.getNodes(), G["tree"])
+    t2 = copy.deepcopy(tree)
+    spec, _, _ = build_creature(t2.getNodes(), [0])
+    _check_layout(spec, t2.getNodes(), G["layout"])
+    _check_control(spec, t2.getNodes(), G["layout"])
+    if site == "top":
+        for k, b in enumerate(spec.bodies):  # bodies at (5, 7 + 0.8 k)
+            assert b._x == 5.0 and b._y == pytest.approx(7 + 0.8 * k, abs=1e-6) and b._angle == 0.0
+
+
+def test_oracle_first_motor_speed_matches_reference(oracle, rough_terrain):
+    """The oracle's controller/PID (o_sin in binary64, float32 narrowing) reproduces the
+    reference's first motorSpeed for every fixture creature."""
+    ot = oracle_terrain(oracle, rough_terrain)
+    for enc in ("direct", "lsystem"):
+        for case in load("layout_%s.json" % enc)["cases"]:
+            genome, ml = _genome(enc, case["seed"])
+            t2 = copy.deepcopy(genome.create(8))
+            spec, _, _ = build_creature(t2.getNodes(), ml)
+            if not spec.joints:
+                continue
+            w = oracle.World.from_morph(ot, Morphology.from_specs([spec]).as_dict(), 0)
+            w.env_step()
+            assert w.joints()[:, 4].tolist() == case["layout"]["control"][0]["motorSpeed"]
+
+
+def test_morphology_packing():
+    specs = synthetic.lsystem_specs(range(6))
+    m = Morphology.from_specs(specs, 32)
+    for e, s in enumerate(specs):
+        lo = e * 32
+        assert (m["shape"][lo:lo + 32] != 0).sum() == s.n_bodies == m.n_bodies[e]
+        assert m["parent"][lo] == -1
+        for k, j in enumerate(s.joints):
+            assert m["parent"][lo + j["child"]] == j["parent"] and j["child"] == k + 1
+            assert m["jround"][lo + j["child"]] == s.rounds[k]
+    sub = m.take([4, 1])
+    assert np.array_equal(sub["x"][:32], m["x"][4 * 32:5 * 32]) and np.array_equal(sub["amp"][32:], m["amp"][32:64])
+    rep = Morphology.replicate(specs[0], 5)
+    assert rep.n_envs == 5 and np.array_equal(rep["hx"][:rep.lanes], rep["hx"][-rep.lanes:])

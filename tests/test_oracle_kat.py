@@ -1,0 +1,249 @@
+"""Known-answer tests that pin the CPU oracle (oracle/rem2d_oracle.c).
+
+The reference ships no tests and its engine (Box2D 2.3.10) is not installable here, so these
+analytic checks are what stands between the oracle and "it merely runs".
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import oracle_terrain
+
+H = np.float32(1.0 / 50)
+
+
+def flat(O, n=200, y=5.0):
+    xs = (np.arange(n) * (14 / 30.0)).astype(np.float32)
+    return O.Terrain(xs, np.full(n, y, np.float32))
+
+
+def test_trig_matches_libm(oracle):
+    rng = np.random.RandomState(0)
+    for a in rng.uniform(-60, 60, 4000).astype(np.float32):
+        s, c = oracle.sincosf(float(a))
+        assert s == np.float32(math.sin(float(a))) and c == np.float32(math.cos(float(a)))
+    assert oracle.sincosf(0.0) == (0.0, 1.0)
+    for x in rng.uniform(-1500, 1500, 4000):
+        assert abs(oracle.sin64(x) - math.sin(x)) <= 2.3e-16
+
+
+def test_mass_properties(oracle):
+    # box m = w*h, I = m (w^2+h^2)/12 ; circle m = pi r^2, I = m r^2 / 2  (density 1)
+    for w, h in ((0.5, 0.8), (0.2, 0.8), (1.0, 1.0), (0.73, 0.51)):
+        m, I = oracle.box_mass(w / 2, h / 2)
+        assert m == pytest.approx(w * h, rel=2e-7)
+        assert I == pytest.approx(w * h * (w * w + h * h) / 12, rel=1e-6)
+    for r in (0.25, 0.5, 0.37):
+        m, I = oracle.circle_mass(r)
+        assert m == pytest.approx(math.pi * r * r, rel=3e-7)
+        assert I == pytest.approx(0.5 * math.pi * r ** 4, rel=1e-6)
+
+
+def test_free_fall_parabola(oracle):
+    w = oracle.World(flat(oracle))
+    w.add_box(0.25, 0.4, 5, 20, 0)
+    for n in range(1, 40):
+        w.step()
+        b = w.bodies()[0]
+        # symplectic Euler: v_n = -g h n, y_n = y0 - g h^2 n(n+1)/2
+        assert b[4] == pytest.approx(-10 * 0.02 * n, abs=2e-5)
+        assert b[1] == pytest.approx(20 - 10 * 0.02 ** 2 * n * (n + 1) / 2, abs=2e-4)
+        assert b[0] == 5.0 and b[2] == 0.0
+
+
+def test_max_translation_clamp(oracle):
+    w = oracle.World(flat(oracle))
+    w.set_gravity(0, 0)
+    w.add_box(0.25, 0.25, 5, 50, 0)
+    w.set_velocity(0, 500.0, 0.0, 0.0)
+    w.step()
+    b = w.bodies()[0]
+    assert b[0] == pytest.approx(5 + 2.0, abs=1e-5)  # |h v| clamped to b2_maxTranslation
+    assert b[3] == pytest.approx(100.0, rel=1e-6)
+    w.set_velocity(0, 0.0, 0.0, 1000.0)
+    w.step()
+    assert w.bodies()[0][5] == pytest.approx(0.5 * math.pi / 0.02, rel=1e-6)  # b2_maxRotation / h
+
+
+def test_box_rests_and_sleeps(oracle):
+    w = oracle.World(flat(oracle))
+    w.add_box(0.25, 0.4, 5.0, 5.6, 0)
+    asleep_at = None
+    for n in range(400):
+        w.step()
+        if asleep_at is None and w.bodies()[0][7] == 0:
+            asleep_at = n
+    b = w.bodies()[0]
+    # rests on its skin: gap between cores in [2*polygonRadius - linearSlop, 2*polygonRadius]
+    assert 0.015 - 1e-4 <= b[1] - (5.0 + 0.4) <= 0.02 + 1e-4
+    assert b[3] == 0 and b[4] == 0 and b[5] == 0 and b[7] == 0
+    assert asleep_at is not None and asleep_at >= 25  # b2_timeToSleep = 0.5 s = 25 steps
+    # normal impulses carry the weight: sum = m g h
+    tot = sum(float(f[:2].sum()) for k in range(1) for f in [w.contacts(0)[1][i] for i in range(len(w.contacts(0)[1]))])
+    assert tot == pytest.approx(0.5 * 0.8 * 10 * 0.02, rel=2e-3)
+
+
+def test_friction_deceleration(oracle):
+    # mu = sqrt(0.1 * 2.5) = 0.5 -> a = mu g = 5 m/s^2
+    w = oracle.World(flat(oracle), flags=oracle.FLAG_NO_SLEEP)
+    w.add_box(0.4, 0.25, 5.0, 5.265, 0)
+    for _ in range(60):
+        w.step()
+    w.set_velocity(0, 3.0, 0.0, 0.0)
+    v = []
+    for _ in range(20):
+        w.step()
+        v.append(w.bodies()[0][3])
+    dec = -(v[15] - v[5]) / (10 * 0.02)
+    assert dec == pytest.approx(5.0, rel=0.03)
+
+
+def test_two_body_free_flight_momentum(oracle):
+    w = oracle.World(flat(oracle))
+    w.set_gravity(0, 0)
+    a = w.add_box(0.25, 0.4, 5, 30, 0)
+    b = w.add_box(0.25, 0.4, 5, 30.8, 0)
+    j = w.add_joint(a, b, 0, 0.4, 0, -0.4)
+    mass = w.mass()
+    m = mass[:, 2]
+    I = mass[:, 3]
+    prev_rel = 0.0
+    for n in range(50):
+        w.set_motor_speed(j, 2.0 if n < 25 else -1.0)
+        w.step()
+        s = w.bodies()
+        p = (m[:, None] * s[:, 3:5]).sum(0)
+        assert abs(p[0]) < 2e-5 and abs(p[1]) < 2e-5  # no external force: linear momentum stays 0
+        com = (m[:, None] * s[:, 0:2]).sum(0) / m.sum()
+        L = sum(I[k] * s[k, 5] + m[k] * ((s[k, 0] - com[0]) * s[k, 4] - (s[k, 1] - com[1]) * s[k, 3]) for k in range(2))
+        assert abs(L) < 3e-4  # motor torque is internal: angular momentum stays 0
+        rel = s[1, 5] - s[0, 5]
+        # |delta omega_rel| per step <= h * maxMotorTorque * (1/I_A + 1/I_B)  (+ constraint coupling slack)
+        assert abs(rel - prev_rel) <= 0.02 * 50 * (1 / I[0] + 1 / I[1]) * 4.5
+        prev_rel = rel
+        ang = s[1, 2] - s[0, 2]
+        assert abs(ang) <= math.pi / 2 + 2 * math.pi / 180 * 1.5
+    # the anchors stay together (point constraint)
+    s = w.bodies()
+    pa = (s[0, 0] - math.sin(s[0, 2]) * 0.4, s[0, 1] + math.cos(s[0, 2]) * 0.4)
+    pb = (s[1, 0] + math.sin(s[1, 2]) * 0.4, s[1, 1] - math.cos(s[1, 2]) * 0.4)
+    assert math.hypot(pa[0] - pb[0], pa[1] - pb[1]) < 0.01
+
+
+def test_joint_limit_pulls_back(oracle):
+    # child attached at relative angle pi (outside +-pi/2): position solver rotates it back <= 8 deg/iter
+    w = oracle.World(flat(oracle))
+    w.set_gravity(0, 0)
+    a = w.add_box(0.25, 0.4, 5, 30, 0)
+    b = w.add_box(0.25, 0.4, 5, 29.2, math.pi)
+    w.add_joint(a, b, 0, -0.4, 0, -0.4)
+    for _ in range(5):
+        w.step()
+    s = w.bodies()
+    assert abs(s[1, 2] - s[0, 2]) <= math.pi / 2 + 2 * math.pi / 180 + 1e-3
+    assert w.joints()[0, 5] == 2  # e_atUpperLimit
+
+
+def test_manifold_box_on_edge(oracle):
+    w = oracle.World(flat(oracle))
+    # box spanning one edge only: edge 10 covers x in [4.667, 5.133]
+    w.add_box(0.1, 0.1, 4.9, 5.115, 0)
+    w.step()
+    c, f = w.contacts(0)
+    touching = c[c[:, 1] > 0]
+    assert len(touching) == 1
+    e = touching[0]
+    assert e[0] == 10 and e[1] == 2 and e[2] == 1  # edge index, two points, e_faceA
+    man = w.manifold(0, int(np.argmax(c[:, 1] > 0)))
+    assert man[0] == 0.0 and man[1] == 1.0  # local normal (0, 1)
+    # feature ids: reference face 0 on the edge (typeA = face), incident vertices 0 and 1 of the box (typeB = vertex)
+    keys = sorted((int(e[4]) & 0xffffffff, int(e[5]) & 0xffffffff))
+    assert keys == sorted((0 | (0 << 8) | (1 << 16) | (0 << 24), 0 | (1 << 8) | (1 << 16) | (0 << 24)))
+
+
+def test_manifold_circle_regions(oracle):
+    t = flat(oracle)
+    # interior of edge 10 -> e_faceA, one point
+    w = oracle.World(t)
+    w.add_circle(0.25, 4.9, 5.25, 0)
+    w.step()
+    c, _ = w.contacts(0)
+    row = c[(c[:, 0] == 10)][0]
+    assert row[1] == 1 and row[2] == 1 and (int(row[4]) >> 16) & 0xff == 1
+    # isolated edge end: one-edge terrain, circle beyond the second vertex -> e_circles on vertex 1
+    t2 = oracle.Terrain(np.array([0.0, 1.0], np.float32), np.array([5.0, 5.0], np.float32))
+    w = oracle.World(t2)
+    w.set_gravity(0, 0)
+    w.add_circle(0.25, 1.1, 5.2, 0)
+    w.step()
+    c, _ = w.contacts(0)
+    assert len(c) == 1 and c[0][1] == 1 and c[0][2] == 0 and (int(c[0][4]) & 0xff) == 1
+    # at the join of two separate edge bodies both report a contact (no ghost vertices)
+    w = oracle.World(t)
+    w.add_circle(0.25, float(np.float32(11 * 14 / 30.0)), 5.25, 0)
+    w.step()
+    c, _ = w.contacts(0)
+    assert sorted(c[c[:, 1] > 0][:, 0].tolist()) == [10, 11]
+
+
+def test_pair_list_is_lifo_by_creation(oracle):
+    w = oracle.World(flat(oracle))
+    w.add_box(0.5, 0.25, 5.0, 5.3, 0)  # spans edges 9..11(12)
+    w.step()
+    c, _ = w.contacts(0)
+    edges = c[:, 0].tolist()
+    assert edges == sorted(edges, reverse=True)  # created in ascending proxy order, head-inserted
+
+
+def test_island_joint_order_matches_host(oracle):
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    specs = synthetic.lsystem_specs(range(24)) + synthetic.direct_specs(range(24))
+    t = flat(oracle)
+    for s in specs:
+        if not s.joints:
+            continue
+        m = Morphology.from_specs([s]).as_dict()
+        w = oracle.World.from_morph(t, m, 0)
+        w.step()
+        assert w.island_joint_order().tolist() == s.island_order
+        # rounds respect the island order among joints sharing a body
+        seen = {}
+        for k in s.island_order:
+            a, b = s.joints[k]["parent"], s.joints[k]["child"]
+            assert s.rounds[k] > max(seen.get(a, -1), seen.get(b, -1))
+            seen[a] = seen[b] = s.rounds[k]
+
+
+def test_continuous_stops_tunnelling(oracle):
+    t = flat(oracle)
+    lows = {}
+    for flags in (0, oracle.FLAG_CONTINUOUS):
+        w = oracle.World(t, flags=flags)
+        w.add_circle(0.25, 5.0, 7.0, 0)
+        w.set_velocity(0, 0.0, -60.0, 0.0)
+        lo = 1e9
+        for _ in range(12):
+            w.step()
+            lo = min(lo, w.bodies()[0][1])
+        lows[flags] = lo
+        if flags:
+            assert w.toi_events >= 1
+    assert lows[oracle.FLAG_CONTINUOUS] > 5.0 + 0.25 - 0.02  # stopped at the surface
+    assert lows[0] < lows[oracle.FLAG_CONTINUOUS]             # discrete step penetrates / tunnels
+
+
+def test_env_step_reward_and_wall_of_death(oracle, rough_terrain):
+    from gym_rem2d_amd import synthetic
+    m = synthetic.chain_population(1, 4, "top").as_dict()
+    w = oracle.World.from_morph(oracle_terrain(oracle, rough_terrain), m, 0)
+    for k in range(1, 140):
+        r, d = w.env_step()
+        x = float(w.bodies()[0][0])
+        if 0.04 * k > x or x < 0:
+            assert r == -100 and d == 1
+            break
+        assert r == x and d == 0
+    else:
+        pytest.fail("wall of death never caught the creature")

@@ -1,0 +1,190 @@
+"""HIP stepper vs the CPU oracle, through the C ABI, on a real MI355X (pytest -m gpu).
+
+Bar: bit-exact -- integers (pair lists, feature keys, point counts, limit states, awake flags)
+AND floats (poses, velocities, impulses): both sides evaluate the same binary32 expression
+sequence without FMA contraction, so `==` is the tolerance.  (-0.0 == +0.0 counts as equal.)
+"""
+import numpy as np
+import pytest
+
+from conftest import oracle_terrain
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from gym_rem2d_amd.world import BatchedWorld
+    return BatchedWorld
+
+
+def _populations():
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    ls = synthetic.lsystem_specs(range(48), mutate_odd=True)
+    return {
+        "chain4_top": synthetic.chain_population(20, 4, "top"),
+        "chain4_left": synthetic.chain_population(16, 4, "left"),
+        "chain4_right": synthetic.chain_population(7, 4, "right"),
+        "chain8_top": synthetic.chain_population(9, 8, "top"),
+        "lsystem_k32": Morphology.from_specs(ls, 32),
+        "lsystem_k16": Morphology.from_specs([s for s in ls if s.n_bodies <= 16], 16),
+        "direct": Morphology.from_specs(synthetic.direct_specs(range(40))),
+        "pairs_k2": Morphology.from_specs([s for s in synthetic.lsystem_specs(range(60)) if s.n_bodies <= 2], 2),
+    }
+
+
+def _run_gpu(BatchedWorld, morph, terrain, chunks, flags=0):
+    w = BatchedWorld(morph.n_envs, morph.lanes, flags)
+    w.set_terrain(terrain)
+    w.reset(morph)
+    snaps = []
+    for c in chunks:
+        w.step(c)
+        snaps.append(w.bodies())
+    return w, snaps
+
+
+@pytest.mark.parametrize("name", ["chain4_top", "chain4_left", "chain4_right", "chain8_top", "lsystem_k32",
+                                  "lsystem_k16", "direct", "pairs_k2"])
+@pytest.mark.parametrize("terrain_name", ["flat", "rough"])
+def test_trajectory_bit_exact(gpu, oracle, flat_terrain, rough_terrain, name, terrain_name):
+    morph = _populations()[name]
+    terrain = flat_terrain if terrain_name == "flat" else rough_terrain
+    chunks = [1, 1, 1, 7, 40, 150, 100]
+    T = sum(chunks)
+    ref = oracle.batch_run(oracle_terrain(oracle, terrain), morph.as_dict(), T, n_threads=8, trace=True)
+    w, snaps = _run_gpu(gpu, morph, terrain, chunks)
+    t = 0
+    for c, s in zip(chunks, snaps):
+        t += c
+        assert np.array_equal(s[..., :3], ref["trace"][t - 1]), "pose mismatch at step %d" % t
+    assert np.array_equal(snaps[-1], ref["bodies"])  # + velocities, sleep time, awake flag
+    assert np.array_equal(w.view("reward").cpu().numpy(), ref["reward"].astype(np.float32))
+    assert np.array_equal(w.view("everdone").cpu().numpy(), ref["done"])
+    assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+    assert int(w.view("err").max()) == 0
+    w.close()
+
+
+def test_contact_and_joint_indices_bit_exact(gpu, oracle, rough_terrain):
+    """Pair lists in list order, manifold point counts/types, feature keys, warm-start impulses,
+    joint impulses / limit states / motor speeds, island ordering inputs."""
+    morph = _populations()["lsystem_k32"]
+    ot = oracle_terrain(oracle, rough_terrain)
+    for T in (1, 30, 120):
+        w, _ = _run_gpu(gpu, morph, rough_terrain, [T])
+        cedge, cinfo = w.view("cedge").cpu().numpy(), w.view("cinfo").cpu().numpy()
+        key = [w.view("ckey0").cpu().numpy(), w.view("ckey1").cpu().numpy()]
+        imp = [w.view(k).cpu().numpy() for k in ("cn0", "cn1", "ct0", "ct1")]
+        ccount = w.view("ccount").cpu().numpy()
+        jst = [w.view(k).cpu().numpy() for k in ("jimpx", "jimpy", "jimpz", "jmotorimp", "jmotorspeed")]
+        jlim = w.view("jlimit").cpu().numpy()
+        for e in range(0, morph.n_envs, 3):
+            ow = oracle.World.from_morph(ot, morph.as_dict(), e)
+            for _ in range(T):
+                ow.env_step()
+            slots = [s for s in range(morph.lanes) if morph["shape"][e * morph.lanes + s] != 0]
+            for b, s in enumerate(slots):
+                oc, of = ow.contacts(b)
+                assert ccount[e, s] == len(oc)
+                for k in range(len(oc)):
+                    assert cedge[k, e, s] == oc[k][0]                      # terrain edge, list order
+                    n = oc[k][1]
+                    assert (cinfo[k, e, s] & 0xff) == n                    # manifold point count
+                    if n > 0:
+                        assert (cinfo[k, e, s] >> 8) == oc[k][2]           # manifold type
+                    for j in range(n):
+                        assert (int(key[j][k, e, s]) & 0xffffffff) == (int(oc[k][4 + j]) & 0xffffffff)
+                        assert imp[j][k, e, s] == of[k][j] and imp[2 + j][k, e, s] == of[k][2 + j]
+            oj = ow.joints()
+            for b, s in enumerate(slots[1:]):
+                for q in range(5):
+                    assert jst[q][e, s] == oj[b][q]
+                assert jlim[e, s] == int(oj[b][5])
+        w.close()
+
+
+def test_multi_step_launch_equals_single_steps(gpu, rough_terrain):
+    morph = _populations()["direct"]
+    _, a = _run_gpu(gpu, morph, rough_terrain, [1] * 60)
+    _, b = _run_gpu(gpu, morph, rough_terrain, [60])
+    _, c = _run_gpu(gpu, morph, rough_terrain, [13, 47])
+    assert np.array_equal(a[-1], b[-1]) and np.array_equal(a[-1], c[-1])
+
+
+def test_sleep_variants_and_single_bodies(gpu, oracle, flat_terrain):
+    """Single-module creatures fall, settle and go to sleep for good (no joint to wake them);
+    both SetAwake variants and doSleep=False follow the oracle."""
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    singles = [s for s in synthetic.lsystem_specs(range(80)) if s.n_bodies == 1][:8]
+    multi = synthetic.lsystem_specs(range(5))
+    morph = Morphology.from_specs(singles + multi, 32)
+    for flags in (0, _lib.FLAG_SLEEP_RESET_ALWAYS, _lib.FLAG_NO_SLEEP):
+        ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), morph.as_dict(), 200, n_threads=8, flags=flags)
+        w, snaps = _run_gpu(gpu, morph, flat_terrain, [200], flags)
+        assert np.array_equal(snaps[-1], ref["bodies"])
+        if flags == 0:
+            assert np.all(snaps[-1][:len(singles), 0, 7] == 0)  # asleep
+        w.close()
+
+
+def test_padding_and_empty_lanes(gpu, oracle, rough_terrain):
+    from gym_rem2d_amd import synthetic
+    morph = synthetic.chain_population(5, 3, "top", lanes=4)  # 5 envs -> padded to 16, lane 3 empty
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), 50, n_threads=2)
+    w, snaps = _run_gpu(gpu, morph, rough_terrain, [50])
+    assert w.n_envs_padded == 16 and snaps[-1].shape == (5, 4, 8)
+    assert np.array_equal(snaps[-1], ref["bodies"])
+    assert np.all(snaps[-1][:, 3, :] == 0)
+    w.close()
+
+
+def test_full_size_replicas_agree(gpu, oracle, flat_terrain):
+    """BASELINE full size (65 536 creatures): size-independent properties.  Identical creatures
+    stay identical in every env (checksum of checksums), and equal the oracle's single env;
+    a tiled heterogeneous population reproduces its 256 unique members in every tile."""
+    import torch
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    N = 65536
+    morph = synthetic.chain_population(N, 4, "left")
+    w, _ = _run_gpu(gpu, morph, flat_terrain, [100])
+    one = oracle.batch_run(oracle_terrain(oracle, flat_terrain), synthetic.chain_population(1, 4, "left").as_dict(), 100)
+    for k in ("px", "py", "ang", "vx", "vy", "w"):
+        v = w.view(k)
+        assert bool((v == v[0:1]).all())
+    assert np.array_equal(w.bodies()[0], one["bodies"][0])
+    w.close()
+    uniq = Morphology.from_specs([s for s in synthetic.lsystem_specs(range(400)) if s.n_bodies <= 16][:256], 16)
+    tiled = uniq.take(np.arange(N) % 256)
+    w, _ = _run_gpu(gpu, tiled, flat_terrain, [60])
+    ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), uniq.as_dict(), 60, n_threads=8)
+    px = w.view("px").view(N // 256, 256, 16)
+    assert bool((px == px[0:1]).all())
+    assert np.array_equal(w.bodies()[:256], ref["bodies"])
+    assert int(w.view("err").max()) == 0
+    w.close()
+
+
+def test_determinism(gpu, rough_terrain):
+    morph = _populations()["lsystem_k16"]
+    _, a = _run_gpu(gpu, morph, rough_terrain, [150])
+    _, b = _run_gpu(gpu, morph, rough_terrain, [150])
+    assert np.array_equal(a[-1], b[-1])
+
+
+def test_call_order_errors(gpu):
+    from gym_rem2d_amd import _lib, synthetic
+    w = gpu(4, 4)
+    with pytest.raises(_lib.Rem2dError, match="set_terrain"):
+        w.step(1)
+    with pytest.raises(ValueError):
+        w.reset(synthetic.chain_population(3, 4))
+    w.close()
