@@ -64,9 +64,11 @@ def cpu_baseline(morphs, terrain, budget_s=12.0):
     xs, ys, _ = terrain.f32()
     ot = O.Terrain(xs, ys, None, terrain.friction)
     cores = os.cpu_count() or 1
-    # sample: a proportional slice of every bucket, 64 creatures in total, 50 steps; repeat to fill the budget
+    # sample: a proportional slice of every bucket (>= 4 creatures per host thread), 50 steps from reset;
+    # repeated until the time budget is used
     total = sum(m.n_envs for m in morphs)
-    take = [max(1, int(round(64 * m.n_envs / total))) for m in morphs]
+    want = min(total, max(512, 4 * cores))
+    take = [min(m.n_envs, max(1, int(round(want * m.n_envs / total)))) for m in morphs]
     subs = [m.take(np.linspace(0, m.n_envs - 1, t).astype(np.int64)) for m, t in zip(morphs, take)]
     steps, done_steps, t0 = 50, 0, time.time()
     n = sum(s.n_envs for s in subs)
@@ -90,6 +92,8 @@ def main():
     ap.add_argument("--workload", default="lsystem", choices=["lsystem", "chain8", "chain4"])
     ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (default: config size)")
     ap.add_argument("--steps-per-launch", type=int, default=10)
+    ap.add_argument("--settle", type=int, default=60,
+                    help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,6 +137,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    run(args.settle)
     run(args.warmup)
     for w, _ in env.worlds:
         w.enable_timing(True)
@@ -178,6 +183,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload_desc, "envs_per_gpu": n_envs, "steps_per_launch": spl,
+                       "settle_steps": args.settle,
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,
                        "parallelism": "population sharded over %d GPU(s), no per-step collective" % world,
                        "solver_errors": err},

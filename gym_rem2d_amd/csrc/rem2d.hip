@@ -230,6 +230,15 @@ template <int K> DEV int group_or(int v) {
     for (int o = 1; o < K; o <<= 1) v |= __shfl_xor(v, o);
     return v;
 }
+// Mailbox hand-off between lanes of ONE wave (workgroup == wavefront): LDS operations of a wave
+// execute in issue order, so all that is needed is that the compiler neither reorders the LDS
+// accesses across this point nor forwards stale values: release + acquire at workgroup scope
+// (lowers to s_waitcnt lgkmcnt(0)); no s_barrier is required.
+DEV void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 DEV int wave_max(int v) {
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -563,7 +572,7 @@ struct StepArgs { int nSteps; float dt; int velIters, posIters; };
 
 template <int K>
 __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ volatile float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
+    __shared__ float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
     const int lane = threadIdx.x;
     const int gl = blockIdx.x * WAVE + lane;
     const int env = gl / K;
@@ -877,6 +886,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
             }
             if (nRounds > 0) {
                 mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                lds_sync();
                 for (int r = 0; r < nRounds; ++r) {
                     if (jround == r) {
                         V2 vA = mk(mbox[0][pl], mbox[1][pl]);
@@ -891,6 +901,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                         mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
                         mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
                     }
+                    lds_sync();
                 }
                 vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
             }
@@ -898,6 +909,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
             for (int it = 0; it < A.velIters; ++it) {
                 if (nRounds > 0) {
                     mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                    lds_sync();
                     for (int r = 0; r < nRounds; ++r) {
                         if (jround == r) {
                             V2 vA = mk(mbox[0][pl], mbox[1][pl]);
@@ -961,6 +973,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                             mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
                             mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
                         }
+                        lds_sync();
                     }
                     vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
                 }
@@ -1138,6 +1151,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 int jointOk = 1;
                 if (nRounds > 0) {
                     mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
+                    lds_sync();
                     for (int r = 0; r < nRounds; ++r) {
                         if (jround == r && !envSolved) {
                             V2 cA = mk(mbox[0][pl], mbox[1][pl]);
@@ -1188,6 +1202,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                             mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
                             jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
                         }
+                        lds_sync();
                     }
                     px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
                 }

@@ -2870,7 +2870,7 @@ int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, in
     if (K > O_MAX_BODIES) return -1;
     (void)n_threads;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
 #endif
     for (int e = 0; e < N; ++e) {
         o_world *w = rem2d_oracle_world_from_morph(t, m, e, flags);
