@@ -16,7 +16,7 @@ FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
 
 CONTACT_SLOTS = 16
-SOLVER_SLOTS = 4
+SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
 

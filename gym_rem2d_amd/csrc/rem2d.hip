@@ -35,7 +35,8 @@
 #include "rem2d.h"
 
 #define KC REM2D_CONTACT_SLOTS
-#define KT REM2D_SOLVER_SLOTS
+#define KT REM2D_SOLVER_SLOTS   // touching contacts per body that can enter the solver
+#define KR 3                    // ... of which this many are register resident in the velocity loop
 #define WAVE 64
 #define SCR_WORDS 9 // manifold scratch words per solver slot
 
@@ -64,27 +65,36 @@ enum { LIM_INACTIVE = 0, LIM_AT_LOWER = 1, LIM_AT_UPPER = 2, LIM_EQUAL = 3 };
 enum { CF_VERTEX = 0, CF_FACE = 1 };
 
 // =====================================================================================
-// state arena
+// state arena: field-major with ONE stride per group, so that a kernel address is
+//   (scalar group base + field * stride)  +  (32-bit per-lane byte offset shared by all fields)
+// i.e. global_load/store with an SGPR base and one VGPR offset -- no per-array address VGPRs.
 // =====================================================================================
-struct FieldDesc { int kind; int dtype; }; // kind: 0 per lane, 1 per contact slot x lane, 2 per creature
-static const FieldDesc kFields[REM2D_F_COUNT] = {
-    // per lane float (27)
-    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
-    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
-    // per lane int (6)
-    {0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 1},
-    // per lane double (5)
-    {0, 2}, {0, 2}, {0, 2}, {0, 2}, {0, 2},
-    // contact slots (8): edge, info (int), key0, key1 (int), n0 n1 t0 t1 (float)
-    {1, 1}, {1, 1}, {1, 1}, {1, 1}, {1, 0}, {1, 0}, {1, 0}, {1, 0},
-    // per creature: wod f64, fitness f64, reward f32, done, everdone, frozen, steps i32, invdt0 f32, newfix, err,
-    // positers, toievents i32
-    {2, 2}, {2, 2}, {2, 0}, {2, 1}, {2, 1}, {2, 1}, {2, 1}, {2, 0}, {2, 1}, {2, 1}, {2, 1}, {2, 1}};
+struct FieldDesc { int group; int index; int dtype; }; // group: 0 lane4, 1 lane8, 2 slot4, 3 env4, 4 env8
+enum { G_LANE4 = 0, G_LANE8 = 1, G_SLOT4 = 2, G_ENV4 = 3, G_ENV8 = 4 };
+// per-lane 4-byte fields, same order as REM2D_F_PX .. REM2D_F_CCOUNT
+enum {
+    L_PX = 0, L_PY, L_ANG, L_VX, L_VY, L_W, L_SLEEPT, L_HX, L_HY, L_INVM, L_INVI, L_FATLX, L_FATLY, L_FATUX, L_FATUY,
+    L_JAX, L_JAY, L_JBX, L_JBY, L_JTORQUE, L_JLOWER, L_JUPPER, L_JIMPX, L_JIMPY, L_JIMPZ, L_JMOTORIMP, L_JMOTORSPEED,
+    L_SHAPE, L_PARENT, L_JROUND, L_AWAKE, L_JLIMIT, L_CCOUNT, L4_COUNT
+};
+enum { D_CAMP = 0, D_CPHASE, D_CFREQ, D_COFFSET, D_CISTATE, L8_COUNT };
+enum { C_EDGE = 0, C_INFO, C_KEY0, C_KEY1, C_N0, C_N1, C_T0, C_T1, S4_COUNT };
+enum { E_REWARD = 0, E_DONE, E_EVERDONE, E_FROZEN, E_STEPS, E_INVDT0, E_NEWFIX, E_ERR, E_POSITERS, E_TOIEVENTS, E4_COUNT };
+enum { E_WOD = 0, E_FITNESS, E8_COUNT };
+
+static FieldDesc field_desc(int f) {
+    FieldDesc d;
+    if (f <= REM2D_F_CCOUNT) { d.group = G_LANE4; d.index = f; d.dtype = f >= REM2D_F_SHAPE ? 1 : 0; }
+    else if (f <= REM2D_F_CISTATE) { d.group = G_LANE8; d.index = f - REM2D_F_CAMP; d.dtype = 2; }
+    else if (f <= REM2D_F_CT1) { d.group = G_SLOT4; d.index = f - REM2D_F_CEDGE; d.dtype = f <= REM2D_F_CKEY1 ? 1 : 0; }
+    else if (f == REM2D_F_WOD || f == REM2D_F_FITNESS) { d.group = G_ENV8; d.index = f - REM2D_F_WOD; d.dtype = 2; }
+    else { d.group = G_ENV4; d.index = f - REM2D_F_REWARD; d.dtype = (f == REM2D_F_REWARD || f == REM2D_F_INVDT0) ? 0 : 1; }
+    return d;
+}
 
 struct Layout {
     int Np, Lp, K;
-    size_t off[REM2D_F_COUNT];
-    size_t count[REM2D_F_COUNT];
+    size_t groupOff[5];
     size_t total;
 };
 static Layout make_layout(const rem2d_world_cfg *cfg) {
@@ -94,19 +104,28 @@ static Layout make_layout(const rem2d_world_cfg *cfg) {
     L.Np = (cfg->n_envs + perWave - 1) / perWave * perWave;
     L.Lp = L.Np * cfg->lanes;
     size_t o = 0;
-    // 8-byte fields first so that everything stays naturally aligned
-    for (int pass = 0; pass < 2; ++pass)
-        for (int f = 0; f < REM2D_F_COUNT; ++f) {
-            bool wide = kFields[f].dtype == 2;
-            if ((pass == 0) != wide) continue;
-            size_t n = kFields[f].kind == 0 ? (size_t)L.Lp : kFields[f].kind == 1 ? (size_t)L.Lp * KC : (size_t)L.Np;
-            L.off[f] = o;
-            L.count[f] = n;
-            o += n * (wide ? 8 : 4);
-            o = (o + 255) & ~(size_t)255;
-        }
+    const size_t sizes[5] = {(size_t)L4_COUNT * L.Lp * 4, (size_t)L8_COUNT * L.Lp * 8, (size_t)S4_COUNT * KC * L.Lp * 4,
+                             (size_t)E4_COUNT * L.Np * 4, (size_t)E8_COUNT * L.Np * 8};
+    const int order[5] = {G_LANE8, G_ENV8, G_LANE4, G_SLOT4, G_ENV4}; // 8-byte groups first
+    for (int k = 0; k < 5; ++k) {
+        L.groupOff[order[k]] = o;
+        o += sizes[order[k]];
+        o = (o + 255) & ~(size_t)255;
+    }
     L.total = o;
     return L;
+}
+static void field_place(const Layout &L, int f, size_t *off, size_t *count, int *dtype) {
+    FieldDesc d = field_desc(f);
+    size_t n = 0, esz = d.dtype == 2 ? 8 : 4;
+    switch (d.group) {
+    case G_LANE4: case G_LANE8: n = (size_t)L.Lp; break;
+    case G_SLOT4: n = (size_t)L.Lp * KC; break;
+    default: n = (size_t)L.Np; break;
+    }
+    if (off) *off = L.groupOff[d.group] + (size_t)d.index * n * esz;
+    if (count) *count = n;
+    if (dtype) *dtype = d.dtype;
 }
 
 struct Terrain {
@@ -118,22 +137,22 @@ struct Terrain {
 };
 
 struct State {
-    float *px, *py, *ang, *vx, *vy, *w, *sleepT, *hx, *hy, *invM, *invI, *fatLx, *fatLy, *fatUx, *fatUy;
-    float *jAx, *jAy, *jBx, *jBy, *jTorque, *jLower, *jUpper, *jImpX, *jImpY, *jImpZ, *jMotorImp, *jMotorSpeed;
-    int *shape, *parent, *jround, *awake, *jLimit, *cCount;
-    double *cAmp, *cPhase, *cFreq, *cOffset, *cIstate;
-    int *cEdge, *cInfo;
-    unsigned *cKey0, *cKey1;
-    float *cN0, *cN1, *cT0, *cT1;
-    double *wod, *fitness;
-    float *reward;
-    int *done, *everDone, *frozen, *steps;
-    float *invDt0;
-    int *newFix, *err, *posIters, *toiEvents;
-    float *scr; // handle-owned manifold scratch [KT*SCR_WORDS][Lp]
-    int Lp, Np, nEnvs;
-    unsigned flags;
+    char *lane4, *lane8, *slot4, *env4, *env8; // group bases inside the caller's arena
+    float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
+    unsigned Lp, Np, nEnvs, flags;
 };
+// accessors (S, gl and env must be in scope where they are used)
+#define LF(f) (*(float *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))
+#define LI(f) (*(int *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))
+#define LD(f) (*(double *)(S.lane8 + (size_t)(f) * ((size_t)S.Lp * 8) + (gl) * 8u))
+#define CF(f, o32) (*(float *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
+#define CI(f, o32) (*(int *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
+#define CU(f, o32) (*(unsigned *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
+#define EF(f) (*(float *)(S.env4 + (size_t)(f) * ((size_t)S.Np * 4) + (env) * 4u))
+#define EI(f) (*(int *)(S.env4 + (size_t)(f) * ((size_t)S.Np * 4) + (env) * 4u))
+#define ED(f) (*(double *)(S.env8 + (size_t)(f) * ((size_t)S.Np * 8) + (env) * 8u))
+// scratch word k of the record that starts at 32-bit word offset base32 (= word0 * Lp + gl)
+#define SW(base32, k) (*(float *)((char *)S.scr + ((base32) + (unsigned)(k) * S.Lp) * 4u))
 
 // =====================================================================================
 // device math (b2Math.h operand order)
@@ -506,48 +525,49 @@ struct ContactC { // one touching contact (terrain A static, body B = this lane)
     float i11, i12, i22;      // normalMass = K^-1 (symmetric)
     int count;                // solver point count (block solver may drop to 1)
 };
+#define CC_WORDS 21
 
 // b2ContactManager::AddPair: head-insert into the body's pair list
-DEV void pairs_insert_front(const State &S, int gl, int &count, int edge, int &err) {
+DEV void pairs_insert_front(const State &S, unsigned gl, int &count, int edge, int &err) {
     if (count >= KC) { err |= REM2D_ERR_PAIR_OVERFLOW; return; }
     for (int s = count; s > 0; --s) {
-        size_t d = (size_t)s * S.Lp + gl, f = (size_t)(s - 1) * S.Lp + gl;
-        S.cEdge[d] = S.cEdge[f];
-        S.cInfo[d] = S.cInfo[f];
-        S.cKey0[d] = S.cKey0[f];
-        S.cKey1[d] = S.cKey1[f];
-        S.cN0[d] = S.cN0[f];
-        S.cN1[d] = S.cN1[f];
-        S.cT0[d] = S.cT0[f];
-        S.cT1[d] = S.cT1[f];
+        unsigned d = (unsigned)s * S.Lp + gl, f = (unsigned)(s - 1) * S.Lp + gl;
+        CI(C_EDGE, d) = CI(C_EDGE, f);
+        CI(C_INFO, d) = CI(C_INFO, f);
+        CU(C_KEY0, d) = CU(C_KEY0, f);
+        CU(C_KEY1, d) = CU(C_KEY1, f);
+        CF(C_N0, d) = CF(C_N0, f);
+        CF(C_N1, d) = CF(C_N1, f);
+        CF(C_T0, d) = CF(C_T0, f);
+        CF(C_T1, d) = CF(C_T1, f);
     }
-    S.cEdge[gl] = edge;
-    S.cInfo[gl] = 0;
-    S.cKey0[gl] = 0u;
-    S.cKey1[gl] = 0u;
-    S.cN0[gl] = 0.0f;
-    S.cN1[gl] = 0.0f;
-    S.cT0[gl] = 0.0f;
-    S.cT1[gl] = 0.0f;
+    CI(C_EDGE, gl) = edge;
+    CI(C_INFO, gl) = 0;
+    CU(C_KEY0, gl) = 0u;
+    CU(C_KEY1, gl) = 0u;
+    CF(C_N0, gl) = 0.0f;
+    CF(C_N1, gl) = 0.0f;
+    CF(C_T0, gl) = 0.0f;
+    CF(C_T1, gl) = 0.0f;
     ++count;
 }
-DEV void pairs_remove(const State &S, int gl, int &count, int s) {
+DEV void pairs_remove(const State &S, unsigned gl, int &count, int s) {
     for (int k = s; k + 1 < count; ++k) {
-        size_t d = (size_t)k * S.Lp + gl, f = (size_t)(k + 1) * S.Lp + gl;
-        S.cEdge[d] = S.cEdge[f];
-        S.cInfo[d] = S.cInfo[f];
-        S.cKey0[d] = S.cKey0[f];
-        S.cKey1[d] = S.cKey1[f];
-        S.cN0[d] = S.cN0[f];
-        S.cN1[d] = S.cN1[f];
-        S.cT0[d] = S.cT0[f];
-        S.cT1[d] = S.cT1[f];
+        unsigned d = (unsigned)k * S.Lp + gl, f = (unsigned)(k + 1) * S.Lp + gl;
+        CI(C_EDGE, d) = CI(C_EDGE, f);
+        CI(C_INFO, d) = CI(C_INFO, f);
+        CU(C_KEY0, d) = CU(C_KEY0, f);
+        CU(C_KEY1, d) = CU(C_KEY1, f);
+        CF(C_N0, d) = CF(C_N0, f);
+        CF(C_N1, d) = CF(C_N1, f);
+        CF(C_T0, d) = CF(C_T0, f);
+        CF(C_T1, d) = CF(C_T1, f);
     }
     --count;
-    S.cEdge[(size_t)count * S.Lp + gl] = -1;
+    CI(C_EDGE, (unsigned)count * S.Lp + gl) = -1;
 }
 // b2BroadPhase::UpdatePairs for one moved body proxy: new pairs in ascending edge (= proxy id) order
-DEV bool find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2 flo, V2 fhi, int &err) {
+DEV bool find_new_pairs(const State &S, const Terrain &T, unsigned gl, int &count, V2 flo, V2 fhi, int &err) {
     bool added = false;
     int lo = (int)floorf((flo.x - 0.25f - T.x0) * T.invPitch) - 1;
     int hi = (int)floorf((fhi.x + 0.25f - T.x0) * T.invPitch) + 1;
@@ -556,7 +576,7 @@ DEV bool find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2
     for (int e = lo; e <= hi; ++e) {
         if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), flo, fhi)) continue;
         bool exists = false;
-        for (int s = 0; s < count; ++s) exists |= (S.cEdge[(size_t)s * S.Lp + gl] == e);
+        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == e);
         if (!exists) {
             pairs_insert_front(S, gl, count, e, err);
             added = true; // b2ContactManager::AddPair wakes both bodies
@@ -565,58 +585,238 @@ DEV bool find_new_pairs(const State &S, const Terrain &T, int gl, int &count, V2
     return added;
 }
 
+// ---- b2ContactSolver pieces for one (static terrain, this body) constraint ----
+// ctor + InitializeVelocityConstraints: b2WorldManifold with xfA = identity, radiusA = polygonRadius
+DEV void contact_setup(ContactC &c, int mtype, int mcount, V2 ln, V2 lp, V2 p0, V2 p1, V2 cB, Rot q, float mB, float iB,
+                       float radiusB, float n0, float t0, float n1, float t1) {
+    c.count = mcount;
+    c.n0 = n0; c.t0 = t0; c.n1 = n1; c.t1 = t1;
+    V2 normal, w0, w1 = mk(0.0f, 0.0f);
+    const float radiusA = B2_POLYGON_RADIUS;
+    if (mtype == MF_CIRCLES) {
+        normal = mk(1.0f, 0.0f);
+        V2 pointA = lp;
+        V2 pointB = xmul(q, cB, p0);
+        if (vdist2(pointA, pointB) > B2_EPSILON * B2_EPSILON) {
+            normal = vsub(pointB, pointA);
+            vnormalize(normal);
+        }
+        V2 cA = vadd(pointA, vscale(radiusA, normal));
+        V2 cBp = vsub(pointB, vscale(radiusB, normal));
+        w0 = vscale(0.5f, vadd(cA, cBp));
+    } else if (mtype == MF_FACE_A) {
+        normal = ln;
+        V2 planePoint = lp;
+        V2 clip = xmul(q, cB, p0);
+        V2 cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
+        V2 cBp = vsub(clip, vscale(radiusB, normal));
+        w0 = vscale(0.5f, vadd(cA, cBp));
+        if (mcount > 1) {
+            clip = xmul(q, cB, p1);
+            cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
+            cBp = vsub(clip, vscale(radiusB, normal));
+            w1 = vscale(0.5f, vadd(cA, cBp));
+        }
+    } else {
+        V2 nB = rmul(q, ln);
+        V2 planePoint = xmul(q, cB, lp);
+        V2 clip = p0;
+        V2 cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
+        V2 cA = vsub(clip, vscale(radiusA, nB));
+        w0 = vscale(0.5f, vadd(cA, cBp));
+        if (mcount > 1) {
+            clip = p1;
+            cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
+            cA = vsub(clip, vscale(radiusA, nB));
+            w1 = vscale(0.5f, vadd(cA, cBp));
+        }
+        normal = vneg(nB);
+    }
+    c.normal = normal;
+    V2 tangent = vcross_vs(normal, 1.0f);
+    c.rB0 = vsub(w0, cB);
+    c.rB1 = vsub(w1, cB);
+    {
+        float rnB = vcross(c.rB0, normal);
+        float kNormal = mB + iB * rnB * rnB;
+        c.nm0 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+        float rtB = vcross(c.rB0, tangent);
+        float kTangent = mB + iB * rtB * rtB;
+        c.tm0 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+    }
+    c.nm1 = c.tm1 = 0.0f;
+    c.k11 = c.k12 = c.k22 = c.i11 = c.i12 = c.i22 = 0.0f;
+    if (mcount > 1) {
+        float rnB = vcross(c.rB1, normal);
+        float kNormal = mB + iB * rnB * rnB;
+        c.nm1 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+        float rtB = vcross(c.rB1, tangent);
+        float kTangent = mB + iB * rtB * rtB;
+        c.tm1 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+        float rn1B = vcross(c.rB0, normal), rn2B = vcross(c.rB1, normal);
+        float k11 = mB + iB * rn1B * rn1B;
+        float k22 = mB + iB * rn2B * rn2B;
+        float k12 = mB + iB * rn1B * rn2B;
+        const float k_maxConditionNumber = 1000.0f;
+        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+            c.k11 = k11; c.k12 = k12; c.k22 = k22;
+            float det = k11 * k22 - k12 * k12;
+            if (det != 0.0f) det = 1.0f / det;
+            c.i11 = det * k22;
+            c.i12 = -det * k12;
+            c.i22 = det * k11;
+        } else {
+            c.count = 1;
+        }
+    }
+}
+// WarmStart
+DEV void contact_warm_start(const ContactC &c, float mB, float iB, float &vx, float &vy, float &w) {
+    V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
+    V2 P = vadd(vscale(c.n0, normal), vscale(c.t0, tangent));
+    w += iB * vcross(c.rB0, P);
+    vx += mB * P.x; vy += mB * P.y;
+    if (c.count > 1) {
+        P = vadd(vscale(c.n1, normal), vscale(c.t1, tangent));
+        w += iB * vcross(c.rB1, P);
+        vx += mB * P.x; vy += mB * P.y;
+    }
+}
+// SolveVelocityConstraints for one contact (friction first, then normal / 2-point block LCP)
+DEV void contact_solve(ContactC &c, float mB, float iB, float friction, float &vx, float &vy, float &w) {
+    V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
+    V2 vB = mk(vx, vy);
+    float wB = w;
+    {
+        V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
+        float vt = vdot(dv, tangent) - 0.0f;
+        float lambda = c.tm0 * (-vt);
+        float maxFriction = friction * c.n0;
+        float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t0;
+        c.t0 = newImpulse;
+        V2 P = vscale(lambda, tangent);
+        vB = vadd(vB, vscale(mB, P));
+        wB += iB * vcross(c.rB0, P);
+    }
+    if (c.count > 1) {
+        V2 dv = vadd(vB, vcross_sv(wB, c.rB1));
+        float vt = vdot(dv, tangent) - 0.0f;
+        float lambda = c.tm1 * (-vt);
+        float maxFriction = friction * c.n1;
+        float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t1;
+        c.t1 = newImpulse;
+        V2 P = vscale(lambda, tangent);
+        vB = vadd(vB, vscale(mB, P));
+        wB += iB * vcross(c.rB1, P);
+    }
+    if (c.count == 1) {
+        V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
+        float vn = vdot(dv, normal);
+        float lambda = -c.nm0 * (vn - 0.0f);
+        float newImpulse = fmax32(c.n0 + lambda, 0.0f);
+        lambda = newImpulse - c.n0;
+        c.n0 = newImpulse;
+        V2 P = vscale(lambda, normal);
+        vB = vadd(vB, vscale(mB, P));
+        wB += iB * vcross(c.rB0, P);
+    } else {
+        V2 a = mk(c.n0, c.n1);
+        V2 dv1 = vadd(vB, vcross_sv(wB, c.rB0));
+        V2 dv2 = vadd(vB, vcross_sv(wB, c.rB1));
+        float vn1 = vdot(dv1, normal), vn2 = vdot(dv2, normal);
+        V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
+        b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
+        V2 x;
+        bool solved = false;
+        x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y)); // case 1
+        solved = x.x >= 0.0f && x.y >= 0.0f;
+        if (!solved) { // case 2
+            x.x = -c.nm0 * b.x;
+            x.y = 0.0f;
+            vn2 = c.k12 * x.x + b.y;
+            solved = x.x >= 0.0f && vn2 >= 0.0f;
+        }
+        if (!solved) { // case 3
+            x.x = 0.0f;
+            x.y = -c.nm1 * b.y;
+            vn1 = c.k12 * x.y + b.x;
+            solved = x.y >= 0.0f && vn1 >= 0.0f;
+        }
+        if (!solved) { // case 4
+            x.x = 0.0f;
+            x.y = 0.0f;
+            solved = b.x >= 0.0f && b.y >= 0.0f;
+        }
+        if (solved) {
+            V2 d = vsub(x, a);
+            V2 P1 = vscale(d.x, normal), P2 = vscale(d.y, normal);
+            vB = vadd(vB, vscale(mB, vadd(P1, P2)));
+            wB += iB * (vcross(c.rB0, P1) + vcross(c.rB1, P2));
+            c.n0 = x.x;
+            c.n1 = x.y;
+        }
+    }
+    vx = vB.x; vy = vB.y; w = wB;
+}
+// constraints beyond the register-resident ones live in handle scratch ([word][lane], coalesced)
+DEV void cc_store(const State &S, unsigned cb, const ContactC &c) {
+    SW(cb, 0) = c.normal.x; SW(cb, 1) = c.normal.y; SW(cb, 2) = c.rB0.x; SW(cb, 3) = c.rB0.y;
+    SW(cb, 4) = c.rB1.x; SW(cb, 5) = c.rB1.y; SW(cb, 6) = c.nm0; SW(cb, 7) = c.nm1; SW(cb, 8) = c.tm0;
+    SW(cb, 9) = c.tm1; SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+    SW(cb, 14) = c.k11; SW(cb, 15) = c.k12; SW(cb, 16) = c.k22; SW(cb, 17) = c.i11; SW(cb, 18) = c.i12;
+    SW(cb, 19) = c.i22; SW(cb, 20) = __int_as_float(c.count);
+}
+DEV void cc_load(const State &S, unsigned cb, ContactC &c) {
+    c.normal = mk(SW(cb, 0), SW(cb, 1)); c.rB0 = mk(SW(cb, 2), SW(cb, 3)); c.rB1 = mk(SW(cb, 4), SW(cb, 5));
+    c.nm0 = SW(cb, 6); c.nm1 = SW(cb, 7); c.tm0 = SW(cb, 8); c.tm1 = SW(cb, 9);
+    c.n0 = SW(cb, 10); c.n1 = SW(cb, 11); c.t0 = SW(cb, 12); c.t1 = SW(cb, 13);
+    c.k11 = SW(cb, 14); c.k12 = SW(cb, 15); c.k22 = SW(cb, 16); c.i11 = SW(cb, 17); c.i12 = SW(cb, 18);
+    c.i22 = SW(cb, 19); c.count = __float_as_int(SW(cb, 20));
+}
+
 // =====================================================================================
 // the step kernel
 // =====================================================================================
 struct StepArgs { int nSteps; float dt; int velIters, posIters; };
 
+// Register budget: what the 180-iteration velocity loop touches stays in VGPRs (body velocity,
+// joint effective-mass terms and impulses, KR contact constraints); everything else (pose
+// history, shape, fat AABB, anchors, controller, per-creature bookkeeping) is re-read from
+// HBM/L2 at its point of use once per step, so that the kernel fits two waves per SIMD.
 template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
+__global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
     __shared__ float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
     const int lane = threadIdx.x;
-    const int gl = blockIdx.x * WAVE + lane;
-    const int env = gl / K;
+    const unsigned gl0 = blockIdx.x * WAVE + lane;
+    const unsigned env0 = gl0 / K;
+    unsigned gl = gl0, env = env0;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
-    const size_t Lp = (size_t)S.Lp;
+    const unsigned Lp = S.Lp;
+    // scratch: manifolds [KT][SCR_WORDS][Lp], then overflow constraints [KT-KR][CC_WORDS][Lp]
 
-    // ---- load per-lane state ----
-    const int shape = S.shape[gl];
+    const int shape = LI(L_SHAPE);
     const bool active = shape != SHAPE_NONE;
-    const float hx = S.hx[gl], hy = S.hy[gl], mB = S.invM[gl], iB = S.invI[gl];
-    const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
-    float px = S.px[gl], py = S.py[gl], ang = S.ang[gl], vx = S.vx[gl], vy = S.vy[gl], w = S.w[gl];
-    float sleepT = S.sleepT[gl];
-    int awake = S.awake[gl];
-    V2 fatLo = mk(S.fatLx[gl], S.fatLy[gl]), fatHi = mk(S.fatUx[gl], S.fatUy[gl]);
-    int cCount = S.cCount[gl];
-    // joint (this lane = body B, parent lane = body A)
-    const int parent = S.parent[gl];
+    const float mB = LF(L_INVM), iB = LF(L_INVI);
+    float px = LF(L_PX), py = LF(L_PY), ang = LF(L_ANG), vx = LF(L_VX), vy = LF(L_VY), w = LF(L_W);
+    float sleepT = LF(L_SLEEPT);
+    int awake = LI(L_AWAKE);
+    int cCount = LI(L_CCOUNT);
+    const int parent = LI(L_PARENT);
     const bool hasJoint = active && parent >= 0;
     const int pl = base + (parent >= 0 ? parent : 0);
-    const V2 anchorA = mk(S.jAx[gl], S.jAy[gl]), anchorB = mk(S.jBx[gl], S.jBy[gl]);
-    const float jTorque = S.jTorque[gl], jLower = S.jLower[gl], jUpper = S.jUpper[gl];
-    const int jround = hasJoint ? S.jround[gl] : -1;
-    float impX = S.jImpX[gl], impY = S.jImpY[gl], impZ = S.jImpZ[gl], motorImp = S.jMotorImp[gl];
-    int limitState = S.jLimit[gl];
-    float motorSpeed = S.jMotorSpeed[gl];
-    const double cAmp = S.cAmp[gl], cPhase = S.cPhase[gl], cFreq = S.cFreq[gl], cOffset = S.cOffset[gl];
-    double cIstate = S.cIstate[gl];
+    const int jround = hasJoint ? LI(L_JROUND) : -1;
+    float impX = LF(L_JIMPX), impY = LF(L_JIMPY), impZ = LF(L_JIMPZ), motorImp = LF(L_JMOTORIMP);
+    int limitState = LI(L_JLIMIT);
+    float motorSpeed = LF(L_JMOTORSPEED);
     const float mA = __shfl(mB, pl), iA = __shfl(iB, pl);
     const int nRounds = wave_max(jround) + 1;
-    // does any lane of this creature hang off me?  (SetMotorSpeed wakes both bodies)
-    int childMask = 0;
-    {
-        int pm = hasJoint ? (1 << parent) : 0;
-        childMask = group_or<K>(pm);
-    }
-    const bool jointed = hasJoint || ((childMask >> sub) & 1);
-    // per-creature scalars (every lane keeps a copy)
-    double wod = S.wod[env], fitness = S.fitness[env];
-    float invDt0 = S.invDt0[env];
-    int newFix = S.newFix[env], err = 0, frozen = S.frozen[env], stepIdx = S.steps[env];
-    int done = S.done[env], everDone = S.everDone[env], lastPosIters = S.posIters[env];
-    float reward = S.reward[env];
+    const int childMask = group_or<K>(hasJoint ? (1 << parent) : 0);
+    const bool jointed = hasJoint || ((childMask >> sub) & 1); // SetMotorSpeed wakes both bodies
+    float invDt0 = EF(E_INVDT0);
+    int newFix = EI(E_NEWFIX), err = 0, lastPosIters = EI(E_POSITERS);
 
     const float h = A.dt;
     const float inv_dt = h > 0.0f ? 1.0f / h : 0.0f;
@@ -625,13 +825,17 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
     const bool allowSleep = (S.flags & REM2D_FLAG_NO_SLEEP) == 0;
 
     for (int step = 0; step < A.nSteps; ++step) {
-        // =============== Modular2D.step: wod, controllers, PID -> motorSpeed ===============
-        wod += 0.04;
+        // Launder the lane / creature offsets once per step: otherwise LLVM hoists every field's
+        // 64-bit address out of the step loop (60+ VGPR pairs) and then spills them.  With the
+        // offsets opaque per step, accesses select as global_load/store vdst, voffset, saddr.
+        asm volatile("" : "+v"(gl), "+v"(env));
+        // =============== Modular2D.step: controllers, PID -> motorSpeed ===============
         {
             float angParent = __shfl(ang, pl);
             if (hasJoint) {
-                cIstate += cFreq;
-                double target = (cAmp * dev_sin(cIstate + cPhase)) + cOffset;
+                double ist = LD(D_CISTATE) + LD(D_CFREQ);
+                LD(D_CISTATE) = ist;
+                double target = (LD(D_CAMP) * dev_sin(ist + LD(D_CPHASE))) + LD(D_COFFSET);
                 float jointAngle = ang - angParent - 0.0f;
                 double speed = (target - (double)jointAngle) * 1.9;
                 motorSpeed = (float)speed;
@@ -643,6 +847,9 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
         }
         // =============== b2World::Step ===============
         const float dtRatio = invDt0 * h;
+        const float hx = LF(L_HX), hy = LF(L_HY);
+        const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
+        V2 fatLo = mk(LF(L_FATLX), LF(L_FATLY)), fatHi = mk(LF(L_FATUX), LF(L_FATUY));
         if (newFix) { // FindNewContacts for freshly created fixtures
             if (active && find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err)) {
                 if (sleepResetAlways || !awake) sleepT = 0.0f;
@@ -657,11 +864,11 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
         if (active && awake) {
             int s = 0;
             while (s < cCount) {
-                size_t o = (size_t)s * Lp + gl;
-                int e = S.cEdge[o];
+                unsigned o = (unsigned)s * Lp + gl;
+                int e = CI(C_EDGE, o);
                 if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), fatLo, fatHi)) {
                     // b2ContactManager::Destroy wakes the bodies of a touching contact
-                    if ((S.cInfo[o] & 0xff) > 0 && sleepResetAlways) sleepT = 0.0f;
+                    if ((CI(C_INFO, o) & 0xff) > 0 && sleepResetAlways) sleepT = 0.0f;
                     pairs_remove(S, gl, cCount, s);
                     continue;
                 }
@@ -670,10 +877,10 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, mk(px, py), q);
                 else collide_edge_circle(m, e1, e2, hx, mk(px, py));
                 // b2Contact::Update: carry impulses over by feature id
-                int oldCount = S.cInfo[o] & 0xff;
+                int oldCount = CI(C_INFO, o) & 0xff;
                 if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed
-                unsigned ok0 = S.cKey0[o], ok1 = S.cKey1[o];
-                float on0 = S.cN0[o], on1 = S.cN1[o], ot0 = S.cT0[o], ot1 = S.cT1[o];
+                unsigned ok0 = CU(C_KEY0, o), ok1 = CU(C_KEY1, o);
+                float on0 = CF(C_N0, o), on1 = CF(C_N1, o), ot0 = CF(C_T0, o), ot1 = CF(C_T1, o);
                 float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
                 if (m.count > 0) {
                     if (oldCount > 0 && ok0 == m.k0) { n0 = on0; t0 = ot0; }
@@ -683,25 +890,25 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                     if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
                     else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
                 }
-                S.cInfo[o] = m.count | (m.type << 8);
-                S.cKey0[o] = m.k0;
-                S.cKey1[o] = m.k1;
-                S.cN0[o] = n0;
-                S.cN1[o] = n1;
-                S.cT0[o] = t0;
-                S.cT1[o] = t1;
+                CI(C_INFO, o) = m.count | (m.type << 8);
+                CU(C_KEY0, o) = m.k0;
+                CU(C_KEY1, o) = m.k1;
+                CF(C_N0, o) = n0;
+                CF(C_N1, o) = n1;
+                CF(C_T0, o) = t0;
+                CF(C_T1, o) = t1;
                 if (m.count > 0) {
                     if (nTouch < KT) {
-                        float *sc = S.scr + (size_t)nTouch * SCR_WORDS * Lp + gl;
-                        sc[0 * Lp] = __int_as_float(m.type | (m.count << 8));
-                        sc[1 * Lp] = m.ln.x;
-                        sc[2 * Lp] = m.ln.y;
-                        sc[3 * Lp] = m.lp.x;
-                        sc[4 * Lp] = m.lp.y;
-                        sc[5 * Lp] = m.p0.x;
-                        sc[6 * Lp] = m.p0.y;
-                        sc[7 * Lp] = m.p1.x;
-                        sc[8 * Lp] = m.p1.y;
+                        const unsigned sb = (unsigned)(nTouch * SCR_WORDS) * S.Lp + gl;
+                        SW(sb, 0) = __int_as_float(m.type | (m.count << 8));
+                        SW(sb, 1) = m.ln.x;
+                        SW(sb, 2) = m.ln.y;
+                        SW(sb, 3) = m.lp.x;
+                        SW(sb, 4) = m.lp.y;
+                        SW(sb, 5) = m.p0.x;
+                        SW(sb, 6) = m.p0.y;
+                        SW(sb, 7) = m.p1.x;
+                        SW(sb, 8) = m.p1.y;
                         slotPack |= (unsigned)s << (4 * nTouch);
                         ++nTouch;
                     } else {
@@ -714,8 +921,6 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
         // =============== b2World::Solve ===============
         // the creature is one island; it is simulated iff any of its bodies is awake
         const int envAwake = group_or<K>(active && awake ? 1 : 0);
-        float c0x = px, c0y = py, a0 = ang;
-        bool moved = false;
         if (envAwake) {
             if (active && (!awake || sleepResetAlways)) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
             // ---- integrate velocities (gravity (0,-10), no forces, no damping) ----
@@ -727,127 +932,47 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 wz *= 1.0f / (1.0f + h * 0.0f);
                 vx = v.x; vy = v.y; w = wz;
             }
-            // ---- contact constraints: b2ContactSolver ctor + InitializeVelocityConstraints ----
-            ContactC cc[KT];
+            // ---- contact constraints: b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart ----
+            ContactC cc[KR];
+            const bool anyOverflow = __any(nTouch > KR ? 1 : 0);
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
+            for (int t = 0; t < KR; ++t) {
                 cc[t].count = 0;
                 if (t < nTouch) {
-                    const float *sc = S.scr + (size_t)t * SCR_WORDS * Lp + gl;
-                    int tc = __float_as_int(sc[0]);
-                    int mtype = tc & 0xff, mcount = tc >> 8;
-                    V2 ln = mk(sc[1 * Lp], sc[2 * Lp]), lp = mk(sc[3 * Lp], sc[4 * Lp]);
-                    V2 p0 = mk(sc[5 * Lp], sc[6 * Lp]), p1 = mk(sc[7 * Lp], sc[8 * Lp]);
-                    int ps = (slotPack >> (4 * t)) & 0xf;
-                    size_t o = (size_t)ps * Lp + gl;
-                    ContactC &c = cc[t];
-                    c.count = mcount;
-                    c.n0 = dtRatio * S.cN0[o];
-                    c.t0 = dtRatio * S.cT0[o];
-                    c.n1 = dtRatio * S.cN1[o];
-                    c.t1 = dtRatio * S.cT1[o];
-                    // b2WorldManifold::Initialize with xfA = identity, radiusA = polygonRadius
-                    V2 cB = mk(px, py);
-                    V2 normal, w0, w1 = mk(0.0f, 0.0f);
-                    const float radiusA = B2_POLYGON_RADIUS;
-                    if (mtype == MF_CIRCLES) {
-                        normal = mk(1.0f, 0.0f);
-                        V2 pointA = lp;
-                        V2 pointB = xmul(q, cB, p0);
-                        if (vdist2(pointA, pointB) > B2_EPSILON * B2_EPSILON) {
-                            normal = vsub(pointB, pointA);
-                            vnormalize(normal);
-                        }
-                        V2 cA = vadd(pointA, vscale(radiusA, normal));
-                        V2 cBp = vsub(pointB, vscale(radiusB, normal));
-                        w0 = vscale(0.5f, vadd(cA, cBp));
-                    } else if (mtype == MF_FACE_A) {
-                        normal = ln;
-                        V2 planePoint = lp;
-                        V2 clip = xmul(q, cB, p0);
-                        V2 cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
-                        V2 cBp = vsub(clip, vscale(radiusB, normal));
-                        w0 = vscale(0.5f, vadd(cA, cBp));
-                        if (mcount > 1) {
-                            clip = xmul(q, cB, p1);
-                            cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
-                            cBp = vsub(clip, vscale(radiusB, normal));
-                            w1 = vscale(0.5f, vadd(cA, cBp));
-                        }
-                    } else {
-                        V2 nB = rmul(q, ln);
-                        V2 planePoint = xmul(q, cB, lp);
-                        V2 clip = p0;
-                        V2 cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
-                        V2 cA = vsub(clip, vscale(radiusA, nB));
-                        w0 = vscale(0.5f, vadd(cA, cBp));
-                        if (mcount > 1) {
-                            clip = p1;
-                            cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
-                            cA = vsub(clip, vscale(radiusA, nB));
-                            w1 = vscale(0.5f, vadd(cA, cBp));
-                        }
-                        normal = vneg(nB);
-                    }
-                    c.normal = normal;
-                    V2 tangent = vcross_vs(normal, 1.0f);
-                    c.rB0 = vsub(w0, cB);
-                    c.rB1 = vsub(w1, cB);
-                    {
-                        float rnB = vcross(c.rB0, normal);
-                        float kNormal = mB + iB * rnB * rnB;
-                        c.nm0 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-                        float rtB = vcross(c.rB0, tangent);
-                        float kTangent = mB + iB * rtB * rtB;
-                        c.tm0 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-                    }
-                    c.nm1 = c.tm1 = 0.0f;
-                    c.k11 = c.k12 = c.k22 = c.i11 = c.i12 = c.i22 = 0.0f;
-                    if (mcount > 1) {
-                        float rnB = vcross(c.rB1, normal);
-                        float kNormal = mB + iB * rnB * rnB;
-                        c.nm1 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-                        float rtB = vcross(c.rB1, tangent);
-                        float kTangent = mB + iB * rtB * rtB;
-                        c.tm1 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-                        float rn1B = vcross(c.rB0, normal), rn2B = vcross(c.rB1, normal);
-                        float k11 = mB + iB * rn1B * rn1B;
-                        float k22 = mB + iB * rn2B * rn2B;
-                        float k12 = mB + iB * rn1B * rn2B;
-                        const float k_maxConditionNumber = 1000.0f;
-                        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
-                            c.k11 = k11; c.k12 = k12; c.k22 = k22;
-                            float det = k11 * k22 - k12 * k12;
-                            if (det != 0.0f) det = 1.0f / det;
-                            c.i11 = det * k22;
-                            c.i12 = -det * k12;
-                            c.i22 = det * k11;
-                        } else {
-                            c.count = 1;
-                        }
-                    }
-                    // ---- WarmStart ----
-                    {
-                        V2 P = vadd(vscale(c.n0, normal), vscale(c.t0, tangent));
-                        w += iB * vcross(c.rB0, P);
-                        vx += mB * P.x; vy += mB * P.y;
-                        if (c.count > 1) {
-                            P = vadd(vscale(c.n1, normal), vscale(c.t1, tangent));
-                            w += iB * vcross(c.rB1, P);
-                            vx += mB * P.x; vy += mB * P.y;
-                        }
-                    }
+                    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
+                    int tc = __float_as_int(SW(sb, 0));
+                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    contact_setup(cc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
+                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
+                                  dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
+                    contact_warm_start(cc[t], mB, iB, vx, vy, w);
+                }
+            }
+            if (anyOverflow) {
+                for (int t = KR; t < nTouch; ++t) {
+                    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
+                    int tc = __float_as_int(SW(sb, 0));
+                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    ContactC c;
+                    contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
+                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
+                                  dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
+                    contact_warm_start(c, mB, iB, vx, vy, w);
+                    cc_store(S, (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl, c);
                 }
             }
             // ---- joints: InitVelocityConstraints (warm start), in island rounds ----
             V2 rA = mk(0.0f, 0.0f), rB = mk(0.0f, 0.0f);
             float m_exx = 0.0f, m_eyx = 0.0f, m_ezx = 0.0f, m_eyy = 0.0f, m_ezy = 0.0f, m_ezz = 0.0f, motorMass = 0.0f;
             float det33 = 0.0f, det22 = 0.0f, cyz_x = 0.0f, cyz_y = 0.0f, cyz_z = 0.0f;
-            const float maxMotorImpulse = h * jTorque;
+            float maxMotorImpulse = 0.0f;
             {
                 float sA = __shfl(q.s, pl), cA = __shfl(q.c, pl);
                 float aA = __shfl(ang, pl);
                 if (hasJoint) {
+                    const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
+                    const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
+                    maxMotorImpulse = h * LF(L_JTORQUE);
                     Rot qA; qA.s = sA; qA.c = cA;
                     rA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
                     rB = rmul(q, vsub(anchorB, mk(0.0f, 0.0f)));
@@ -932,10 +1057,8 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                                 // impulse = -m_mass.Solve33(Cdot)
                                 float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
                                 float sx = det33 * (bx * cyz_x + by * cyz_y + bz * cyz_z);
-                                // cross(b, ez)
                                 float cbx = by * m_ezz - bz * m_ezy, cby = bz * m_ezx - bx * m_ezz, cbz = bx * m_ezy - by * m_ezx;
                                 float sy = det33 * (m_exx * cbx + m_eyx * cby + m_ezx * cbz);
-                                // cross(ey, b)
                                 float ebx = m_eyy * bz - m_ezy * by, eby = m_ezy * bx - m_eyx * bz, ebz = m_eyx * by - m_eyy * bx;
                                 float sz = det33 * (m_exx * ebx + m_eyx * eby + m_ezx * ebz);
                                 float ix = -sx, iy = -sy, iz = -sz;
@@ -946,7 +1069,6 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                                     bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
                                     if (reduce) {
                                         V2 rhs = vadd(vneg(Cdot1), vscale(impZ, mk(m_ezx, m_ezy)));
-                                        // m_mass.Solve22(rhs): a11=exx a12=eyx a21=exy(=eyx) a22=eyy
                                         float rx = det22 * (m_eyy * rhs.x - m_eyx * rhs.y);
                                         float ry = det22 * (m_exx * rhs.y - m_eyx * rhs.x);
                                         ix = rx; iy = ry; iz = -impZ;
@@ -979,104 +1101,45 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                 }
                 // contacts of this body, in list order
 #pragma unroll
-                for (int t = 0; t < KT; ++t) {
-                    if (t < nTouch) {
-                        ContactC &c = cc[t];
-                        V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
-                        V2 vB = mk(vx, vy);
-                        float wB = w;
-                        // friction first
-                        {
-                            V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
-                            float vt = vdot(dv, tangent) - 0.0f;
-                            float lambda = c.tm0 * (-vt);
-                            float maxFriction = friction * c.n0;
-                            float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
-                            lambda = newImpulse - c.t0;
-                            c.t0 = newImpulse;
-                            V2 P = vscale(lambda, tangent);
-                            vB = vadd(vB, vscale(mB, P));
-                            wB += iB * vcross(c.rB0, P);
-                        }
-                        if (c.count > 1) {
-                            V2 dv = vadd(vB, vcross_sv(wB, c.rB1));
-                            float vt = vdot(dv, tangent) - 0.0f;
-                            float lambda = c.tm1 * (-vt);
-                            float maxFriction = friction * c.n1;
-                            float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
-                            lambda = newImpulse - c.t1;
-                            c.t1 = newImpulse;
-                            V2 P = vscale(lambda, tangent);
-                            vB = vadd(vB, vscale(mB, P));
-                            wB += iB * vcross(c.rB1, P);
-                        }
-                        if (c.count == 1) {
-                            V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
-                            float vn = vdot(dv, normal);
-                            float lambda = -c.nm0 * (vn - 0.0f);
-                            float newImpulse = fmax32(c.n0 + lambda, 0.0f);
-                            lambda = newImpulse - c.n0;
-                            c.n0 = newImpulse;
-                            V2 P = vscale(lambda, normal);
-                            vB = vadd(vB, vscale(mB, P));
-                            wB += iB * vcross(c.rB0, P);
-                        } else {
-                            V2 a = mk(c.n0, c.n1);
-                            V2 dv1 = vadd(vB, vcross_sv(wB, c.rB0));
-                            V2 dv2 = vadd(vB, vcross_sv(wB, c.rB1));
-                            float vn1 = vdot(dv1, normal), vn2 = vdot(dv2, normal);
-                            V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
-                            b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
-                            V2 x;
-                            bool solved = false;
-                            // case 1
-                            x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y));
-                            solved = x.x >= 0.0f && x.y >= 0.0f;
-                            if (!solved) { // case 2
-                                x.x = -c.nm0 * b.x;
-                                x.y = 0.0f;
-                                vn2 = c.k12 * x.x + b.y;
-                                solved = x.x >= 0.0f && vn2 >= 0.0f;
-                            }
-                            if (!solved) { // case 3
-                                x.x = 0.0f;
-                                x.y = -c.nm1 * b.y;
-                                vn1 = c.k12 * x.y + b.x;
-                                solved = x.y >= 0.0f && vn1 >= 0.0f;
-                            }
-                            if (!solved) { // case 4
-                                x.x = 0.0f;
-                                x.y = 0.0f;
-                                solved = b.x >= 0.0f && b.y >= 0.0f;
-                            }
-                            if (solved) {
-                                V2 d = vsub(x, a);
-                                V2 P1 = vscale(d.x, normal), P2 = vscale(d.y, normal);
-                                vB = vadd(vB, vscale(mB, vadd(P1, P2)));
-                                wB += iB * (vcross(c.rB0, P1) + vcross(c.rB1, P2));
-                                c.n0 = x.x;
-                                c.n1 = x.y;
-                            }
-                        }
-                        vx = vB.x; vy = vB.y; w = wB;
+                for (int t = 0; t < KR; ++t)
+                    if (t < nTouch) contact_solve(cc[t], mB, iB, friction, vx, vy, w);
+                if (anyOverflow) {
+                    for (int t = KR; t < nTouch; ++t) {
+                        const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
+                        ContactC c;
+                        cc_load(S, cb, c);
+                        contact_solve(c, mB, iB, friction, vx, vy, w);
+                        SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
                     }
                 }
             }
             // ---- StoreImpulses ----
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
+            for (int t = 0; t < KR; ++t) {
                 if (t < nTouch) {
-                    int ps = (slotPack >> (4 * t)) & 0xf;
-                    size_t o = (size_t)ps * Lp + gl;
-                    S.cN0[o] = cc[t].n0;
-                    S.cT0[o] = cc[t].t0;
+                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    CF(C_N0, o) = cc[t].n0;
+                    CF(C_T0, o) = cc[t].t0;
                     if (cc[t].count > 1) {
-                        S.cN1[o] = cc[t].n1;
-                        S.cT1[o] = cc[t].t1;
+                        CF(C_N1, o) = cc[t].n1;
+                        CF(C_T1, o) = cc[t].t1;
+                    }
+                }
+            }
+            if (anyOverflow) {
+                for (int t = KR; t < nTouch; ++t) {
+                    const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
+                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    CF(C_N0, o) = SW(cb, 10);
+                    CF(C_T0, o) = SW(cb, 12);
+                    if (__float_as_int(SW(cb, 20)) > 1) {
+                        CF(C_N1, o) = SW(cb, 11);
+                        CF(C_T1, o) = SW(cb, 13);
                     }
                 }
             }
             // ---- integrate positions ----
+            const float c0x = px, c0y = py, a0 = ang;
             if (active) {
                 V2 v = mk(vx, vy);
                 V2 translation = vscale(h, v);
@@ -1097,123 +1160,124 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
             // ---- position iterations (per creature early exit) ----
             bool envSolved = false;
             int itersUsed = A.posIters;
-            for (int it = 0; it < A.posIters; ++it) {
-                float minSeparation = 0.0f;
-                if (!envSolved && active) {
-                    for (int t = 0; t < nTouch; ++t) {
-                        const float *sc = S.scr + (size_t)t * SCR_WORDS * Lp + gl;
-                        int tc = __float_as_int(sc[0]);
-                        int mtype = tc & 0xff, mcount = tc >> 8;
-                        V2 ln = mk(sc[1 * Lp], sc[2 * Lp]), lp = mk(sc[3 * Lp], sc[4 * Lp]);
-                        const float radiusA = B2_POLYGON_RADIUS;
-                        for (int j = 0; j < mcount; ++j) {
-                            V2 pj = mk(sc[(5 + 2 * j) * Lp], sc[(6 + 2 * j) * Lp]);
-                            V2 cB = mk(px, py);
-                            V2 normal, point;
-                            float separation;
-                            if (mtype == MF_CIRCLES) {
+            {
+                const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
+                const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
+                for (int it = 0; it < A.posIters; ++it) {
+                    float minSeparation = 0.0f;
+                    if (!envSolved && active) {
+                        for (int t = 0; t < nTouch; ++t) {
+                            const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
+                            int tc = __float_as_int(SW(sb, 0));
+                            int mtype = tc & 0xff, mcount = tc >> 8;
+                            V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
+                            const float radiusA = B2_POLYGON_RADIUS;
+                            for (int j = 0; j < mcount; ++j) {
+                                V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
+                                V2 cB = mk(px, py);
+                                V2 normal, point;
+                                float separation;
                                 Rot qB = rot_set(ang);
-                                V2 pointA = lp;
-                                V2 pointB = xmul(qB, cB, mk(sc[5 * Lp], sc[6 * Lp]));
-                                normal = vsub(pointB, pointA);
-                                vnormalize(normal);
-                                point = vscale(0.5f, vadd(pointA, pointB));
-                                separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                            } else if (mtype == MF_FACE_A) {
-                                Rot qB = rot_set(ang);
-                                normal = ln;
-                                V2 planePoint = lp;
-                                V2 clipPoint = xmul(qB, cB, pj);
-                                separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                point = clipPoint;
-                            } else {
-                                Rot qB = rot_set(ang);
-                                normal = rmul(qB, ln);
-                                V2 planePoint = xmul(qB, cB, lp);
-                                V2 clipPoint = pj;
-                                separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                point = clipPoint;
-                                normal = vneg(normal);
-                            }
-                            V2 rBp = vsub(point, cB);
-                            minSeparation = fmin32(minSeparation, separation);
-                            float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                            float rnB = vcross(rBp, normal);
-                            float Kn = mB + iB * rnB * rnB;
-                            float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                            V2 P = vscale(impulse, normal);
-                            px = px + mB * P.x;
-                            py = py + mB * P.y;
-                            ang += iB * vcross(rBp, P);
-                        }
-                    }
-                }
-                int jointOk = 1;
-                if (nRounds > 0) {
-                    mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
-                    lds_sync();
-                    for (int r = 0; r < nRounds; ++r) {
-                        if (jround == r && !envSolved) {
-                            V2 cA = mk(mbox[0][pl], mbox[1][pl]);
-                            float aA = mbox[2][pl];
-                            V2 cB = mk(mbox[0][lane], mbox[1][lane]);
-                            float aB = mbox[2][lane];
-                            float angularError = 0.0f, positionError = 0.0f;
-                            if (limitState != LIM_INACTIVE) {
-                                float angle = aB - aA - 0.0f;
-                                float limitImpulse = 0.0f;
-                                if (limitState == LIM_EQUAL) {
-                                    float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
-                                    limitImpulse = -motorMass * C;
-                                    angularError = fabs32(C);
-                                } else if (limitState == LIM_AT_LOWER) {
-                                    float C = angle - jLower;
-                                    angularError = -C;
-                                    C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
-                                    limitImpulse = -motorMass * C;
+                                if (mtype == MF_CIRCLES) {
+                                    V2 pointA = lp;
+                                    V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
+                                    normal = vsub(pointB, pointA);
+                                    vnormalize(normal);
+                                    point = vscale(0.5f, vadd(pointA, pointB));
+                                    separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
+                                } else if (mtype == MF_FACE_A) {
+                                    normal = ln;
+                                    V2 planePoint = lp;
+                                    V2 clipPoint = xmul(qB, cB, pj);
+                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+                                    point = clipPoint;
                                 } else {
-                                    float C = angle - jUpper;
-                                    angularError = C;
-                                    C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
-                                    limitImpulse = -motorMass * C;
+                                    normal = rmul(qB, ln);
+                                    V2 planePoint = xmul(qB, cB, lp);
+                                    V2 clipPoint = pj;
+                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+                                    point = clipPoint;
+                                    normal = vneg(normal);
                                 }
-                                aA -= iA * limitImpulse;
-                                aB += iB * limitImpulse;
+                                V2 rBp = vsub(point, cB);
+                                minSeparation = fmin32(minSeparation, separation);
+                                float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                                float rnB = vcross(rBp, normal);
+                                float Kn = mB + iB * rnB * rnB;
+                                float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+                                V2 P = vscale(impulse, normal);
+                                px = px + mB * P.x;
+                                py = py + mB * P.y;
+                                ang += iB * vcross(rBp, P);
                             }
-                            {
-                                Rot qA = rot_set(aA), qB = rot_set(aB);
-                                V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
-                                V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
-                                V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
-                                positionError = vlen(C);
-                                float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
-                                float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
-                                float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
-                                float det = Kexx * Keyy - Kexy * Kexy;
-                                if (det != 0.0f) det = 1.0f / det;
-                                V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
-                                V2 impulse = vneg(sol);
-                                cA = vsub(cA, vscale(mA, impulse));
-                                aA -= iA * vcross(prA, impulse);
-                                cB = vadd(cB, vscale(mB, impulse));
-                                aB += iB * vcross(prB, impulse);
-                            }
-                            mbox[0][pl] = cA.x; mbox[1][pl] = cA.y; mbox[2][pl] = aA;
-                            mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
-                            jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
                         }
-                        lds_sync();
                     }
-                    px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
+                    int jointOk = 1;
+                    if (nRounds > 0) {
+                        mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
+                        lds_sync();
+                        for (int r = 0; r < nRounds; ++r) {
+                            if (jround == r && !envSolved) {
+                                V2 cA = mk(mbox[0][pl], mbox[1][pl]);
+                                float aA = mbox[2][pl];
+                                V2 cB = mk(mbox[0][lane], mbox[1][lane]);
+                                float aB = mbox[2][lane];
+                                float angularError = 0.0f, positionError = 0.0f;
+                                if (limitState != LIM_INACTIVE) {
+                                    float angle = aB - aA - 0.0f;
+                                    float limitImpulse = 0.0f;
+                                    if (limitState == LIM_EQUAL) {
+                                        float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
+                                        limitImpulse = -motorMass * C;
+                                        angularError = fabs32(C);
+                                    } else if (limitState == LIM_AT_LOWER) {
+                                        float C = angle - jLower;
+                                        angularError = -C;
+                                        C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
+                                        limitImpulse = -motorMass * C;
+                                    } else {
+                                        float C = angle - jUpper;
+                                        angularError = C;
+                                        C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
+                                        limitImpulse = -motorMass * C;
+                                    }
+                                    aA -= iA * limitImpulse;
+                                    aB += iB * limitImpulse;
+                                }
+                                {
+                                    Rot qA = rot_set(aA), qB = rot_set(aB);
+                                    V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
+                                    V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
+                                    V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
+                                    positionError = vlen(C);
+                                    float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
+                                    float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
+                                    float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
+                                    float det = Kexx * Keyy - Kexy * Kexy;
+                                    if (det != 0.0f) det = 1.0f / det;
+                                    V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
+                                    V2 impulse = vneg(sol);
+                                    cA = vsub(cA, vscale(mA, impulse));
+                                    aA -= iA * vcross(prA, impulse);
+                                    cB = vadd(cB, vscale(mB, impulse));
+                                    aB += iB * vcross(prB, impulse);
+                                }
+                                mbox[0][pl] = cA.x; mbox[1][pl] = cA.y; mbox[2][pl] = aA;
+                                mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
+                                jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
+                            }
+                            lds_sync();
+                        }
+                        px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
+                    }
+                    float envMinSep = group_min<K>(minSeparation);
+                    int envJointsOk = group_and<K>(jointOk);
+                    bool okNow = (envMinSep >= -3.0f * B2_LINEAR_SLOP) && envJointsOk;
+                    if (!envSolved && okNow) { envSolved = true; itersUsed = it + 1; }
+                    if (__all(envSolved ? 1 : 0)) break;
                 }
-                float envMinSep = group_min<K>(minSeparation);
-                int envJointsOk = group_and<K>(jointOk);
-                bool okNow = (envMinSep >= -3.0f * B2_LINEAR_SLOP) && envJointsOk;
-                if (!envSolved && okNow) { envSolved = true; itersUsed = it + 1; }
-                if (__all(envSolved ? 1 : 0)) break;
             }
             lastPosIters = itersUsed;
-            // ---- write back / SynchronizeTransform happens lazily (q recomputed at the next use) ----
             // ---- sleep ----
             if (allowSleep) {
                 float myT = FLT_MAX;
@@ -1249,48 +1313,50 @@ __global__ __launch_bounds__(WAVE) void rem2d_step_kernel(State S, Terrain T, St
                     V2 d = vscale(B2_AABB_MULTIPLIER, displacement);
                     if (d.x < 0.0f) flo.x += d.x; else fhi.x += d.x;
                     if (d.y < 0.0f) flo.y += d.y; else fhi.y += d.y;
-                    fatLo = flo; fatHi = fhi;
-                    moved = true;
+                    LF(L_FATLX) = flo.x; LF(L_FATLY) = flo.y; LF(L_FATUX) = fhi.x; LF(L_FATUY) = fhi.y;
+                    if (find_new_pairs(S, T, gl, cCount, flo, fhi, err)) {
+                        if (sleepResetAlways || !awake) sleepT = 0.0f; // AddPair -> SetAwake(true)
+                        awake = 1;
+                    }
                 }
-            }
-            if (moved && find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err)) {
-                if (sleepResetAlways || !awake) sleepT = 0.0f; // AddPair -> SetAwake(true)
-                awake = 1;
             }
         }
         if (h > 0.0f) invDt0 = inv_dt;
-        // =============== reward / done / evaluate() fitness ===============
+        // =============== wod / reward / done / evaluate() fitness (one lane per creature) ===============
         {
             float rootx = __shfl(px, base);
-            double r = (double)rootx;
-            double rew = r;
-            int d = 0;
-            if (r < 0.0) { rew = -100.0; d = 1; }
-            if (wod > r) { rew = -100.0; d = 1; }
-            reward = (float)rew;
-            done = d;
-            everDone |= d;
-            if (!frozen) {
-                if (rew < -10.0) frozen = 1;
-                else if (rew > 100.0) { fitness = rew + (double)(10000 - stepIdx) / 10000.0; frozen = 1; }
-                else if (rew > 0.0) fitness = rew;
+            if (sub == 0) {
+                double wod = ED(E_WOD) + 0.04;
+                ED(E_WOD) = wod;
+                double r = (double)rootx;
+                double rew = r;
+                int d = 0;
+                if (r < 0.0) { rew = -100.0; d = 1; }
+                if (wod > r) { rew = -100.0; d = 1; }
+                EF(E_REWARD) = (float)rew;
+                EI(E_DONE) = d;
+                if (d) EI(E_EVERDONE) = 1;
+                int stepIdx = EI(E_STEPS);
+                if (!EI(E_FROZEN)) {
+                    if (rew < -10.0) EI(E_FROZEN) = 1;
+                    else if (rew > 100.0) { ED(E_FITNESS) = rew + (double)(10000 - stepIdx) / 10000.0; EI(E_FROZEN) = 1; }
+                    else if (rew > 0.0) ED(E_FITNESS) = rew;
+                }
+                EI(E_STEPS) = stepIdx + 1;
             }
-            ++stepIdx;
         }
     }
     // ---- store ----
-    S.px[gl] = px; S.py[gl] = py; S.ang[gl] = ang; S.vx[gl] = vx; S.vy[gl] = vy; S.w[gl] = w;
-    S.sleepT[gl] = sleepT; S.awake[gl] = awake;
-    S.fatLx[gl] = fatLo.x; S.fatLy[gl] = fatLo.y; S.fatUx[gl] = fatHi.x; S.fatUy[gl] = fatHi.y;
-    S.cCount[gl] = cCount;
-    S.jImpX[gl] = impX; S.jImpY[gl] = impY; S.jImpZ[gl] = impZ; S.jMotorImp[gl] = motorImp;
-    S.jLimit[gl] = limitState; S.jMotorSpeed[gl] = motorSpeed;
-    S.cIstate[gl] = cIstate;
+    gl = gl0; env = env0;
+    LF(L_PX) = px; LF(L_PY) = py; LF(L_ANG) = ang; LF(L_VX) = vx; LF(L_VY) = vy; LF(L_W) = w;
+    LF(L_SLEEPT) = sleepT; LI(L_AWAKE) = awake;
+    LI(L_CCOUNT) = cCount;
+    LF(L_JIMPX) = impX; LF(L_JIMPY) = impY; LF(L_JIMPZ) = impZ; LF(L_JMOTORIMP) = motorImp;
+    LI(L_JLIMIT) = limitState; LF(L_JMOTORSPEED) = motorSpeed;
     int envErr = group_or<K>(err);
     if (sub == 0) {
-        S.wod[env] = wod; S.fitness[env] = fitness; S.reward[env] = reward; S.done[env] = done;
-        S.everDone[env] = everDone; S.frozen[env] = frozen; S.steps[env] = stepIdx; S.invDt0[env] = invDt0;
-        S.newFix[env] = newFix; S.err[env] = S.err[env] | envErr; S.posIters[env] = lastPosIters;
+        EF(E_INVDT0) = invDt0;
+        EI(E_NEWFIX) = newFix; EI(E_ERR) = EI(E_ERR) | envErr; EI(E_POSITERS) = lastPosIters;
     }
 }
 
@@ -1336,9 +1402,9 @@ DEV void box_mass(float hx, float hy, float &mass, float &I) { // b2PolygonShape
     I = Ib;
 }
 __global__ void rem2d_reset_kernel(State S, rem2d_morph M, int K) {
-    int gl = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned gl = blockIdx.x * blockDim.x + threadIdx.x;
     if (gl >= S.Lp) return;
-    int env = gl / K, sub = gl % K;
+    unsigned env = gl / (unsigned)K, sub = gl % (unsigned)K;
     bool real = env < S.nEnvs;
     int shape = real ? M.shape[gl] : 0;
     float hx = real ? M.hx[gl] : 0.0f, hy = real ? M.hy[gl] : 0.0f;
@@ -1361,40 +1427,40 @@ __global__ void rem2d_reset_kernel(State S, rem2d_morph M, int K) {
         Ib -= m * vdot(lc, lc);
         invI = Ib > 0.0f ? 1.0f / Ib : 0.0f;
     }
-    S.shape[gl] = shape;
-    S.hx[gl] = hx; S.hy[gl] = hy; S.invM[gl] = invM; S.invI[gl] = invI;
+    LI(L_SHAPE) = shape;
+    LF(L_HX) = hx; LF(L_HY) = hy; LF(L_INVM) = invM; LF(L_INVI) = invI;
     // b2Body ctor + ResetMassData: sweep.c = b2Mul(xf, localCenter = 0)
     Rot q = rot_set(a);
     V2 c = xmul(q, mk(x, y), mk(0.0f, 0.0f));
-    S.px[gl] = c.x; S.py[gl] = c.y; S.ang[gl] = a;
-    S.vx[gl] = 0.0f; S.vy[gl] = 0.0f; S.w[gl] = 0.0f; S.sleepT[gl] = 0.0f;
-    S.awake[gl] = shape != SHAPE_NONE ? 1 : 0;
+    LF(L_PX) = c.x; LF(L_PY) = c.y; LF(L_ANG) = a;
+    LF(L_VX) = 0.0f; LF(L_VY) = 0.0f; LF(L_W) = 0.0f; LF(L_SLEEPT) = 0.0f;
+    LI(L_AWAKE) = shape != SHAPE_NONE ? 1 : 0;
     // b2Fixture::CreateProxies: fat AABB of the initial transform
     AABB bb = body_aabb(shape == SHAPE_NONE ? SHAPE_CIRCLE : shape, hx, hy, mk(x, y), q);
     V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
     V2 lo = vsub(bb.lo, r), hi = vadd(bb.hi, r);
-    S.fatLx[gl] = lo.x; S.fatLy[gl] = lo.y; S.fatUx[gl] = hi.x; S.fatUy[gl] = hi.y;
+    LF(L_FATLX) = lo.x; LF(L_FATLY) = lo.y; LF(L_FATUX) = hi.x; LF(L_FATUY) = hi.y;
     int parent = real && shape != SHAPE_NONE ? M.parent[gl] : -1;
-    S.parent[gl] = parent;
-    S.jround[gl] = real ? M.jround[gl] : 0;
-    S.jAx[gl] = real ? M.ax[gl] : 0.0f; S.jAy[gl] = real ? M.ay[gl] : 0.0f;
-    S.jBx[gl] = real ? M.bx[gl] : 0.0f; S.jBy[gl] = real ? M.by[gl] : 0.0f;
-    S.jTorque[gl] = real ? M.torque[gl] : 0.0f; S.jLower[gl] = real ? M.lower[gl] : 0.0f;
-    S.jUpper[gl] = real ? M.upper[gl] : 0.0f;
-    S.jImpX[gl] = 0.0f; S.jImpY[gl] = 0.0f; S.jImpZ[gl] = 0.0f; S.jMotorImp[gl] = 0.0f; S.jMotorSpeed[gl] = 0.0f;
-    S.jLimit[gl] = LIM_INACTIVE;
-    S.cAmp[gl] = real ? M.amp[gl] : 0.0; S.cPhase[gl] = real ? M.phase[gl] : 0.0; S.cFreq[gl] = real ? M.freq[gl] : 0.0;
-    S.cOffset[gl] = real ? M.offset[gl] : 0.0; S.cIstate[gl] = real ? M.istate[gl] : 0.0;
-    S.cCount[gl] = 0;
+    LI(L_PARENT) = parent;
+    LI(L_JROUND) = real ? M.jround[gl] : 0;
+    LF(L_JAX) = real ? M.ax[gl] : 0.0f; LF(L_JAY) = real ? M.ay[gl] : 0.0f;
+    LF(L_JBX) = real ? M.bx[gl] : 0.0f; LF(L_JBY) = real ? M.by[gl] : 0.0f;
+    LF(L_JTORQUE) = real ? M.torque[gl] : 0.0f; LF(L_JLOWER) = real ? M.lower[gl] : 0.0f;
+    LF(L_JUPPER) = real ? M.upper[gl] : 0.0f;
+    LF(L_JIMPX) = 0.0f; LF(L_JIMPY) = 0.0f; LF(L_JIMPZ) = 0.0f; LF(L_JMOTORIMP) = 0.0f; LF(L_JMOTORSPEED) = 0.0f;
+    LI(L_JLIMIT) = LIM_INACTIVE;
+    LD(D_CAMP) = real ? M.amp[gl] : 0.0; LD(D_CPHASE) = real ? M.phase[gl] : 0.0; LD(D_CFREQ) = real ? M.freq[gl] : 0.0;
+    LD(D_COFFSET) = real ? M.offset[gl] : 0.0; LD(D_CISTATE) = real ? M.istate[gl] : 0.0;
+    LI(L_CCOUNT) = 0;
     for (int s = 0; s < KC; ++s) {
-        size_t o = (size_t)s * S.Lp + gl;
-        S.cEdge[o] = -1; S.cInfo[o] = 0; S.cKey0[o] = 0u; S.cKey1[o] = 0u;
-        S.cN0[o] = 0.0f; S.cN1[o] = 0.0f; S.cT0[o] = 0.0f; S.cT1[o] = 0.0f;
+        unsigned o = (unsigned)s * S.Lp + gl;
+        CI(C_EDGE, o) = -1; CI(C_INFO, o) = 0; CU(C_KEY0, o) = 0u; CU(C_KEY1, o) = 0u;
+        CF(C_N0, o) = 0.0f; CF(C_N1, o) = 0.0f; CF(C_T0, o) = 0.0f; CF(C_T1, o) = 0.0f;
     }
     if (sub == 0) {
-        S.wod[env] = 0.0; S.fitness[env] = 0.0; S.reward[env] = 0.0f; S.done[env] = 0; S.everDone[env] = 0;
-        S.frozen[env] = 0; S.steps[env] = 0; S.invDt0[env] = 0.0f; S.newFix[env] = 1; S.err[env] = 0;
-        S.posIters[env] = 0; S.toiEvents[env] = 0;
+        ED(E_WOD) = 0.0; ED(E_FITNESS) = 0.0; EF(E_REWARD) = 0.0f; EI(E_DONE) = 0; EI(E_EVERDONE) = 0;
+        EI(E_FROZEN) = 0; EI(E_STEPS) = 0; EF(E_INVDT0) = 0.0f; EI(E_NEWFIX) = 1; EI(E_ERR) = 0;
+        EI(E_POSITERS) = 0; EI(E_TOIEVENTS) = 0;
     }
 }
 
@@ -1446,36 +1512,15 @@ extern "C" int32_t rem2d_padded_envs(const rem2d_world_cfg *cfg) {
 
 static void bind_state(rem2d_world *w) {
     State &S = w->S;
-    char *b = w->state;
     const Layout &L = w->L;
-#define P(T, f) reinterpret_cast<T *>(b + L.off[f])
-    S.px = P(float, REM2D_F_PX); S.py = P(float, REM2D_F_PY); S.ang = P(float, REM2D_F_ANG);
-    S.vx = P(float, REM2D_F_VX); S.vy = P(float, REM2D_F_VY); S.w = P(float, REM2D_F_W);
-    S.sleepT = P(float, REM2D_F_SLEEPT); S.hx = P(float, REM2D_F_HX); S.hy = P(float, REM2D_F_HY);
-    S.invM = P(float, REM2D_F_INVM); S.invI = P(float, REM2D_F_INVI);
-    S.fatLx = P(float, REM2D_F_FATLX); S.fatLy = P(float, REM2D_F_FATLY);
-    S.fatUx = P(float, REM2D_F_FATUX); S.fatUy = P(float, REM2D_F_FATUY);
-    S.jAx = P(float, REM2D_F_JAX); S.jAy = P(float, REM2D_F_JAY); S.jBx = P(float, REM2D_F_JBX);
-    S.jBy = P(float, REM2D_F_JBY); S.jTorque = P(float, REM2D_F_JTORQUE); S.jLower = P(float, REM2D_F_JLOWER);
-    S.jUpper = P(float, REM2D_F_JUPPER); S.jImpX = P(float, REM2D_F_JIMPX); S.jImpY = P(float, REM2D_F_JIMPY);
-    S.jImpZ = P(float, REM2D_F_JIMPZ); S.jMotorImp = P(float, REM2D_F_JMOTORIMP);
-    S.jMotorSpeed = P(float, REM2D_F_JMOTORSPEED);
-    S.shape = P(int, REM2D_F_SHAPE); S.parent = P(int, REM2D_F_PARENT); S.jround = P(int, REM2D_F_JROUND);
-    S.awake = P(int, REM2D_F_AWAKE); S.jLimit = P(int, REM2D_F_JLIMIT); S.cCount = P(int, REM2D_F_CCOUNT);
-    S.cAmp = P(double, REM2D_F_CAMP); S.cPhase = P(double, REM2D_F_CPHASE); S.cFreq = P(double, REM2D_F_CFREQ);
-    S.cOffset = P(double, REM2D_F_COFFSET); S.cIstate = P(double, REM2D_F_CISTATE);
-    S.cEdge = P(int, REM2D_F_CEDGE); S.cInfo = P(int, REM2D_F_CINFO);
-    S.cKey0 = P(unsigned, REM2D_F_CKEY0); S.cKey1 = P(unsigned, REM2D_F_CKEY1);
-    S.cN0 = P(float, REM2D_F_CN0); S.cN1 = P(float, REM2D_F_CN1); S.cT0 = P(float, REM2D_F_CT0);
-    S.cT1 = P(float, REM2D_F_CT1);
-    S.wod = P(double, REM2D_F_WOD); S.fitness = P(double, REM2D_F_FITNESS); S.reward = P(float, REM2D_F_REWARD);
-    S.done = P(int, REM2D_F_DONE); S.everDone = P(int, REM2D_F_EVERDONE); S.frozen = P(int, REM2D_F_FROZEN);
-    S.steps = P(int, REM2D_F_STEPS); S.invDt0 = P(float, REM2D_F_INVDT0); S.newFix = P(int, REM2D_F_NEWFIX);
-    S.err = P(int, REM2D_F_ERR); S.posIters = P(int, REM2D_F_POSITERS); S.toiEvents = P(int, REM2D_F_TOIEVENTS);
-#undef P
-    S.Lp = L.Lp;
-    S.Np = L.Np;
-    S.nEnvs = w->cfg.n_envs;
+    S.lane4 = w->state + L.groupOff[G_LANE4];
+    S.lane8 = w->state + L.groupOff[G_LANE8];
+    S.slot4 = w->state + L.groupOff[G_SLOT4];
+    S.env4 = w->state + L.groupOff[G_ENV4];
+    S.env8 = w->state + L.groupOff[G_ENV8];
+    S.Lp = (unsigned)L.Lp;
+    S.Np = (unsigned)L.Np;
+    S.nEnvs = (unsigned)w->cfg.n_envs;
     S.flags = w->cfg.flags;
 }
 
@@ -1487,6 +1532,9 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         return fail(REM2D_E_INVALID, "REM2D_FLAG_CONTINUOUS (SolveTOI) is not implemented on the HIP path yet");
     Layout L = make_layout(cfg);
     if (!state_dev || state_bytes < L.total) return fail(REM2D_E_INVALID, "state buffer missing or too small");
+    // 32-bit per-lane byte offsets: (slots * Lp + lane) * 4 and (scratch words * Lp + lane) * 4 must fit
+    if ((size_t)L.Lp * (KT * SCR_WORDS + (KT - KR) * 21 + 1) * 4 >= ((size_t)1 << 32))
+        return fail(REM2D_E_INVALID, "too many lanes for one world (n_envs * lanes must stay below ~9 million)");
     if (((uintptr_t)state_dev & 255) != 0) return fail(REM2D_E_INVALID, "state buffer must be 256-byte aligned");
     HIP_TRY(hipSetDevice(cfg->device));
     rem2d_world *w = new (std::nothrow) rem2d_world();
@@ -1501,7 +1549,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->launches = 0;
     bind_state(w);
     w->S.scr = nullptr;
-    hipError_t e = hipMalloc((void **)&w->S.scr, (size_t)KT * SCR_WORDS * L.Lp * sizeof(float));
+    hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)KT * SCR_WORDS + (size_t)(KT - KR) * 21) * L.Lp * sizeof(float));
     if (e != hipSuccess) {
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
@@ -1604,7 +1652,7 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
-    dim3 grid(w->L.Lp / WAVE), block(WAVE);
+    dim3 grid((unsigned)w->L.Lp / WAVE), block(WAVE);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (w->timing) {
@@ -1633,9 +1681,9 @@ extern "C" int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream) {
 
 extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
     if (!w || field < 0 || field >= REM2D_F_COUNT) return fail(REM2D_E_INVALID, "bad field id");
-    if (offset_bytes) *offset_bytes = w->L.off[field];
-    if (count) *count = w->L.count[field];
-    if (dtype) *dtype = kFields[field].dtype;
+    int dt = 0;
+    field_place(w->L, field, offset_bytes, count, &dt);
+    if (dtype) *dtype = dt;
     return REM2D_OK;
 }
 

@@ -44,7 +44,7 @@ enum {
 
 #define REM2D_MAX_LANES 32
 #define REM2D_CONTACT_SLOTS 16 /* broadphase pair slots per body */
-#define REM2D_SOLVER_SLOTS 4  /* touching contacts per body that enter the solver */
+#define REM2D_SOLVER_SLOTS 6  /* touching contacts per body that enter the solver */
 
 typedef struct rem2d_world rem2d_world;
 
