@@ -52,9 +52,12 @@ def build_population(workload, n_envs, rank):
     groups = {}
     for s in specs:
         groups.setdefault(lanes_for(s.n_bodies), []).append(s)
+    # creatures of one wave run in lockstep: sort every bucket by (joint rounds, bodies)
+    for k in groups:
+        groups[k].sort(key=lambda s: (max(s.rounds, default=-1), s.n_bodies))
     morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
     return morphs, ("%d random L-System creatures (seeds %d..%d, maxModules=15, <=16 bodies), flat terrain, "
-                    "bucketed by lane count %s" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
+                    "bucketed by lane count %s and sorted by joint rounds" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
 
 
 def cpu_baseline(morphs, terrain, budget_s=12.0):

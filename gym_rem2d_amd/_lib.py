@@ -15,7 +15,7 @@ FLAG_CONTINUOUS = 1
 FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
 
-CONTACT_SLOTS = 16
+CONTACT_SLOTS = 24
 SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2

@@ -197,7 +197,7 @@ DEV V2 xmulT(Rot q, V2 p, V2 v) {
     return mk(q.c * px + q.s * py, -q.s * px + q.c * py);
 }
 
-// ---- trig: the algorithm documented in DESIGN.md ("rem2d trig"), binary64 without FMA ----
+// ---- trig (DESIGN.md "rem2d trig"): binary64 form for the controller's math.sin ----
 DEV void dev_sincos_d(double x, double &s, double &c) {
     const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
                  PIO2_1T = 6.07710050650619224932e-11;
@@ -216,13 +216,25 @@ DEV void dev_sincos_d(double x, double &s, double &c) {
     s = (q == 2 || q == 3) ? -ss : ss;
     c = (q == 1 || q == 2) ? -cc : cc;
 }
-DEV Rot rot_set(float a) {
-    double s, c;
-    dev_sincos_d((double)a, s, c);
-    Rot q;
-    q.s = (float)s;
-    q.c = (float)c;
-    return q;
+// b2Rot::Set -- "rem2d trig" binary32 form: 3-term Cody-Waite reduction by pi/2 and the
+// Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4], every operation a separately rounded binary32 op.
+DEV Rot rot_set(float x) {
+    const float TWO_OVER_PI = 0.63661977236758134308f;
+    const float DP1 = 1.5703125f, DP2 = 4.837512969970703125e-4f, DP3 = 7.54978995489188216e-8f;
+    const float S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
+    const float C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
+    float fn = rintf(x * TWO_OVER_PI);
+    int n = (int)fn;
+    float r = ((x - fn * DP1) - fn * DP2) - fn * DP3;
+    float z = r * r;
+    float ps = r + r * (z * (S1 + z * (S2 + z * S3)));
+    float pc = (1.0f - 0.5f * z) + z * z * (C1 + z * (C2 + z * C3));
+    int q = n & 3;
+    float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    Rot o;
+    o.s = (q == 2 || q == 3) ? -ss : ss;
+    o.c = (q == 1 || q == 2) ? -cc : cc;
+    return o;
 }
 DEV double dev_sin(double x) {
     double s, c;
@@ -909,7 +921,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                         SW(sb, 6) = m.p0.y;
                         SW(sb, 7) = m.p1.x;
                         SW(sb, 8) = m.p1.y;
-                        slotPack |= (unsigned)s << (4 * nTouch);
+                        slotPack |= (unsigned)s << (5 * nTouch);
                         ++nTouch;
                     } else {
                         err |= REM2D_ERR_SOLVER_OVERFLOW;
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                 if (t < nTouch) {
                     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
                     int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
                     contact_setup(cc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
                                   mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
                                   dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
@@ -952,7 +964,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                 for (int t = KR; t < nTouch; ++t) {
                     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
                     int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
                     ContactC c;
                     contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
                                   mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
@@ -1117,7 +1129,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
 #pragma unroll
             for (int t = 0; t < KR; ++t) {
                 if (t < nTouch) {
-                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
                     CF(C_N0, o) = cc[t].n0;
                     CF(C_T0, o) = cc[t].t0;
                     if (cc[t].count > 1) {
@@ -1129,7 +1141,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
             if (anyOverflow) {
                 for (int t = KR; t < nTouch; ++t) {
                     const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
-                    unsigned o = ((slotPack >> (4 * t)) & 0xf) * Lp + gl;
+                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
                     CF(C_N0, o) = SW(cb, 10);
                     CF(C_T0, o) = SW(cb, 12);
                     if (__float_as_int(SW(cb, 20)) > 1) {

@@ -92,7 +92,8 @@ class BatchedModular2D:
             groups.setdefault(lanes_for(s.n_bodies), []).append(e)
         batches = []
         for lanes in sorted(groups):
-            idx = groups[lanes]
+            # creatures of one wave run in lockstep: keep waves homogeneous in joint rounds / size
+            idx = sorted(groups[lanes], key=lambda e: (max(specs[e].rounds, default=-1), specs[e].n_bodies))
             batches.append((Morphology.from_specs([specs[e] for e in idx], lanes), idx))
         self._upload(batches, len(specs))
 

@@ -43,7 +43,7 @@ enum {
 #define REM2D_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
 
 #define REM2D_MAX_LANES 32
-#define REM2D_CONTACT_SLOTS 16 /* broadphase pair slots per body */
+#define REM2D_CONTACT_SLOTS 24 /* broadphase pair slots per body */
 #define REM2D_SOLVER_SLOTS 6  /* touching contacts per body that enter the solver */
 
 typedef struct rem2d_world rem2d_world;

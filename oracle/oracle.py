@@ -197,8 +197,8 @@ class World:
         return out[:n].copy()
 
     def contacts(self, body):
-        out = np.zeros((16, 8), dtype=np.int32)
-        fout = np.zeros((16, 4), dtype=np.float32)
+        out = np.zeros((24, 8), dtype=np.int32)
+        fout = np.zeros((24, 4), dtype=np.float32)
         n = lib().rem2d_oracle_get_contacts(self.h, body, _ptr(out), _ptr(fout))
         return out[:n].copy(), fout[:n].copy()
 

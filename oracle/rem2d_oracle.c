@@ -142,11 +142,27 @@ static void o_sincos_d(double x, double *s, double *c) {
     default: *s = -pc; *c = ps; break;
     }
 }
-void rem2d_oracle_sincosf(float a, float *s, float *c) {
-    double ds, dc;
-    o_sincos_d((double)a, &ds, &dc);
-    *s = (float)ds;
-    *c = (float)dc;
+/* b2Rot::Set: Box2D calls libm sinf/cosf, whose bits are platform specific.  "rem2d trig", binary32
+ * form: n = rintf(x*2/pi); r = ((x - n*DP1) - n*DP2) - n*DP3 (Cody-Waite, pi/2 in three parts);
+ * Cephes sinf/cosf polynomials on [-pi/4, pi/4]; every operation is a separately rounded binary32
+ * operation.  Within ~1 ulp of libm for |x| < 1e3 (tests/test_oracle_kat.py). */
+void rem2d_oracle_sincosf(float x, float *s, float *c) {
+    const float TWO_OVER_PI = 0.63661977236758134308f;
+    const float DP1 = 1.5703125f, DP2 = 4.837512969970703125e-4f, DP3 = 7.54978995489188216e-8f;
+    const float FS1 = -1.6666654611e-1f, FS2 = 8.3321608736e-3f, FS3 = -1.9515295891e-4f;
+    const float FC1 = 4.166664568298827e-2f, FC2 = -1.388731625493765e-3f, FC3 = 2.443315711809948e-5f;
+    float fn = rintf(x * TWO_OVER_PI);
+    int n = (int)fn;
+    float r = ((x - fn * DP1) - fn * DP2) - fn * DP3;
+    float z = r * r;
+    float ps = r + r * (z * (FS1 + z * (FS2 + z * FS3)));
+    float pc = (1.0f - 0.5f * z) + z * z * (FC1 + z * (FC2 + z * FC3));
+    switch (n & 3) {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
+    }
 }
 double rem2d_oracle_sin(double x) {
     double ds, dc;

@@ -30,7 +30,7 @@ extern "C" {
 #define O_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
 
 #define O_MAX_BODIES 32
-#define O_MAX_BODY_CONTACTS 16
+#define O_MAX_BODY_CONTACTS 24
 
 typedef struct o_terrain o_terrain;
 typedef struct o_world o_world;
