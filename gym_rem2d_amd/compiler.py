@@ -166,6 +166,26 @@ def joint_rounds(n_bodies, joints):
     return rounds, order
 
 
+def pipeline_schedule(n_bodies, joints, rounds):
+    """Modulo schedule of the velocity iterations (one tick = a joint slot, then a contact slot).
+
+    Joint k of iteration t fires at tick ``rounds[k] + t*P``; body b's contacts of iteration t at
+    ``offC[b] + t*P`` with ``offC[b]`` = the last joint slot that touches b.  ``P`` is the smallest
+    period for which joint k of iteration t+1 starts strictly after the contact slots (iteration t)
+    of both of its bodies.  Every pair of operations that share a body then runs in Box2D's
+    sequential order (joints in island order, then contacts, iteration after iteration), so the
+    pipelined sweep is bit-identical to the sequential one while the chain of joints no longer
+    serialises a whole iteration."""
+    offC = [0] * n_bodies
+    for k, (a, b) in enumerate(joints):
+        offC[a] = max(offC[a], rounds[k])
+        offC[b] = max(offC[b], rounds[k])
+    period = 1
+    for k, (a, b) in enumerate(joints):
+        period = max(period, max(offC[a], offC[b]) + 1 - rounds[k])
+    return offC, period
+
+
 class CreatureSpec:
     """One creature's bodies/joints after construction."""
 
@@ -175,6 +195,7 @@ class CreatureSpec:
         self.node_slots = node_slots  # node index in tree.nodes -> lane or -1
         pairs = [(j["parent"], j["child"]) for j in self.joints]
         self.rounds, self.island_order = joint_rounds(len(self.bodies), pairs)
+        self.offC, self.period = pipeline_schedule(len(self.bodies), pairs, self.rounds)
 
     @property
     def n_bodies(self):
@@ -259,13 +280,15 @@ class Morphology:
             a[k][lo:lo + K] = -1 if k == "parent" else 0
         for b in spec.bodies:
             i = lo + b.slot
+            # packed schedule: joint round | contact slot << 8 | period << 16 (joint round filled below)
+            a["jround"][i] = (spec.offC[b.slot] << 8) | (spec.period << 16)
             a["shape"][i] = b.shape
             a["hx"][i], a["hy"][i] = b.hx, b.hy
             a["x"][i], a["y"][i], a["angle"][i] = b._x, b._y, b._angle
         for k, j in enumerate(spec.joints):
             i = lo + j["child"]
             a["parent"][i] = j["parent"]
-            a["jround"][i] = spec.rounds[k]
+            a["jround"][i] |= spec.rounds[k]
             for f in ("ax", "ay", "bx", "by", "torque", "lower", "upper"):
                 a[f][i] = j[f]
             a["amp"][i], a["phase"][i], a["freq"][i], a["offset"][i], a["istate"][i] = j["ctrl"]

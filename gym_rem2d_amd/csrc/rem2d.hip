@@ -819,7 +819,10 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
     const int parent = LI(L_PARENT);
     const bool hasJoint = active && parent >= 0;
     const int pl = base + (parent >= 0 ? parent : 0);
-    const int jround = hasJoint ? LI(L_JROUND) : -1;
+    // packed schedule (compiler.pipeline_schedule): joint round | contact slot << 8 | period << 16
+    const int sched = LI(L_JROUND);
+    const int jround = hasJoint ? (sched & 0xff) : -1;
+    const int offC = (sched >> 8) & 0xff, period = (sched >> 16) & 0xff;
     float impX = LF(L_JIMPX), impY = LF(L_JIMPY), impZ = LF(L_JIMPZ), motorImp = LF(L_JMOTORIMP);
     int limitState = LI(L_JLIMIT);
     float motorSpeed = LF(L_JMOTORSPEED);
@@ -1042,88 +1045,101 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                 }
                 vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
             }
-            // ---- velocity iterations ----
-            for (int it = 0; it < A.velIters; ++it) {
-                if (nRounds > 0) {
-                    mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
-                    lds_sync();
-                    for (int r = 0; r < nRounds; ++r) {
-                        if (jround == r) {
-                            V2 vA = mk(mbox[0][pl], mbox[1][pl]);
-                            float wA = mbox[2][pl];
-                            V2 vB = mk(mbox[0][lane], mbox[1][lane]);
-                            float wB = mbox[2][lane];
-                            // motor
-                            if (limitState != LIM_EQUAL) {
-                                float Cdot = wB - wA - motorSpeed;
-                                float impulse = -motorMass * Cdot;
-                                float oldImpulse = motorImp;
-                                motorImp = fclamp(oldImpulse + impulse, -maxMotorImpulse, maxMotorImpulse);
-                                impulse = motorImp - oldImpulse;
-                                wA -= iA * impulse;
-                                wB += iB * impulse;
-                            }
-                            if (limitState != LIM_INACTIVE) {
-                                V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
-                                float Cdot2 = wB - wA;
-                                // impulse = -m_mass.Solve33(Cdot)
-                                float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
-                                float sx = det33 * (bx * cyz_x + by * cyz_y + bz * cyz_z);
-                                float cbx = by * m_ezz - bz * m_ezy, cby = bz * m_ezx - bx * m_ezz, cbz = bx * m_ezy - by * m_ezx;
-                                float sy = det33 * (m_exx * cbx + m_eyx * cby + m_ezx * cbz);
-                                float ebx = m_eyy * bz - m_ezy * by, eby = m_ezy * bx - m_eyx * bz, ebz = m_eyx * by - m_eyy * bx;
-                                float sz = det33 * (m_exx * ebx + m_eyx * eby + m_ezx * ebz);
-                                float ix = -sx, iy = -sy, iz = -sz;
-                                if (limitState == LIM_EQUAL) {
-                                    impX += ix; impY += iy; impZ += iz;
-                                } else {
-                                    float newImpulse = impZ + iz;
-                                    bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
-                                    if (reduce) {
-                                        V2 rhs = vadd(vneg(Cdot1), vscale(impZ, mk(m_ezx, m_ezy)));
-                                        float rx = det22 * (m_eyy * rhs.x - m_eyx * rhs.y);
-                                        float ry = det22 * (m_exx * rhs.y - m_eyx * rhs.x);
-                                        ix = rx; iy = ry; iz = -impZ;
-                                        impX += rx; impY += ry; impZ = 0.0f;
-                                    } else {
-                                        impX += ix; impY += iy; impZ += iz;
-                                    }
-                                }
-                                V2 P = mk(ix, iy);
-                                vA = vsub(vA, vscale(mA, P));
-                                wA -= iA * (vcross(rA, P) + iz);
-                                vB = vadd(vB, vscale(mB, P));
-                                wB += iB * (vcross(rB, P) + iz);
-                            } else {
-                                V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
-                                V2 b = vneg(Cdot);
-                                V2 impulse = mk(det22 * (m_eyy * b.x - m_eyx * b.y), det22 * (m_exx * b.y - m_eyx * b.x));
-                                impX += impulse.x; impY += impulse.y;
-                                vA = vsub(vA, vscale(mA, impulse));
-                                wA -= iA * vcross(rA, impulse);
-                                vB = vadd(vB, vscale(mB, impulse));
-                                wB += iB * vcross(rB, impulse);
-                            }
-                            mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
-                            mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
+            // ---- velocity iterations, software-pipelined across iterations ----
+            // One tick = a joint slot then a contact slot.  Joint (parent, this body) of iteration t fires
+            // at tick jround + t*period, this body's contacts at offC + t*period; the host proves that any
+            // two operations sharing a body keep Box2D's sequential order, so the result is bit-identical
+            // to "for it: all joints in island order; all contacts" while a chain of J joints costs
+            // `period` (2..4) slots per iteration instead of J.  Velocities live in the LDS mailbox.
+            {
+                const int iters = A.velIters;
+                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                lds_sync();
+                int nextJ = (hasJoint && iters > 0) ? jround : 0x7fffffff, leftJ = iters;
+                int nextC = (active && nTouch > 0 && iters > 0) ? offC : 0x7fffffff, leftC = iters;
+                const int nTicks = wave_max((active && iters > 0) ? offC + (iters - 1) * period : -1) + 1;
+                for (int tick = 0; tick < nTicks; ++tick) {
+                    if (tick == nextJ) {
+                        nextJ = (--leftJ > 0) ? nextJ + period : 0x7fffffff;
+                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
+                        float wA = mbox[2][pl];
+                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
+                        float wB = mbox[2][lane];
+                        // motor
+                        if (limitState != LIM_EQUAL) {
+                            float Cdot = wB - wA - motorSpeed;
+                            float impulse = -motorMass * Cdot;
+                            float oldImpulse = motorImp;
+                            motorImp = fclamp(oldImpulse + impulse, -maxMotorImpulse, maxMotorImpulse);
+                            impulse = motorImp - oldImpulse;
+                            wA -= iA * impulse;
+                            wB += iB * impulse;
                         }
-                        lds_sync();
+                        if (limitState != LIM_INACTIVE) {
+                            V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
+                            float Cdot2 = wB - wA;
+                            // impulse = -m_mass.Solve33(Cdot)
+                            float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
+                            float sx = det33 * (bx * cyz_x + by * cyz_y + bz * cyz_z);
+                            float cbx = by * m_ezz - bz * m_ezy, cby = bz * m_ezx - bx * m_ezz, cbz = bx * m_ezy - by * m_ezx;
+                            float sy = det33 * (m_exx * cbx + m_eyx * cby + m_ezx * cbz);
+                            float ebx = m_eyy * bz - m_ezy * by, eby = m_ezy * bx - m_eyx * bz, ebz = m_eyx * by - m_eyy * bx;
+                            float sz = det33 * (m_exx * ebx + m_eyx * eby + m_ezx * ebz);
+                            float ix = -sx, iy = -sy, iz = -sz;
+                            if (limitState == LIM_EQUAL) {
+                                impX += ix; impY += iy; impZ += iz;
+                            } else {
+                                float newImpulse = impZ + iz;
+                                bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
+                                if (reduce) {
+                                    V2 rhs = vadd(vneg(Cdot1), vscale(impZ, mk(m_ezx, m_ezy)));
+                                    float rx = det22 * (m_eyy * rhs.x - m_eyx * rhs.y);
+                                    float ry = det22 * (m_exx * rhs.y - m_eyx * rhs.x);
+                                    ix = rx; iy = ry; iz = -impZ;
+                                    impX += rx; impY += ry; impZ = 0.0f;
+                                } else {
+                                    impX += ix; impY += iy; impZ += iz;
+                                }
+                            }
+                            V2 P = mk(ix, iy);
+                            vA = vsub(vA, vscale(mA, P));
+                            wA -= iA * (vcross(rA, P) + iz);
+                            vB = vadd(vB, vscale(mB, P));
+                            wB += iB * (vcross(rB, P) + iz);
+                        } else {
+                            V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
+                            V2 b = vneg(Cdot);
+                            V2 impulse = mk(det22 * (m_eyy * b.x - m_eyx * b.y), det22 * (m_exx * b.y - m_eyx * b.x));
+                            impX += impulse.x; impY += impulse.y;
+                            vA = vsub(vA, vscale(mA, impulse));
+                            wA -= iA * vcross(rA, impulse);
+                            vB = vadd(vB, vscale(mB, impulse));
+                            wB += iB * vcross(rB, impulse);
+                        }
+                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
+                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
                     }
-                    vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
-                }
-                // contacts of this body, in list order
+                    lds_sync();
+                    if (tick == nextC) { // contacts of this body, in list order
+                        nextC = (--leftC > 0) ? nextC + period : 0x7fffffff;
+                        float cvx = mbox[0][lane], cvy = mbox[1][lane], cw = mbox[2][lane];
 #pragma unroll
-                for (int t = 0; t < KR; ++t)
-                    if (t < nTouch) contact_solve(cc[t], mB, iB, friction, vx, vy, w);
-                if (anyOverflow) {
-                    for (int t = KR; t < nTouch; ++t) {
-                        const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
-                        ContactC c;
-                        cc_load(S, cb, c);
-                        contact_solve(c, mB, iB, friction, vx, vy, w);
-                        SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+                        for (int t = 0; t < KR; ++t)
+                            if (t < nTouch) contact_solve(cc[t], mB, iB, friction, cvx, cvy, cw);
+                        if (nTouch > KR) {
+                            for (int t = KR; t < nTouch; ++t) {
+                                const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
+                                ContactC c;
+                                cc_load(S, cb, c);
+                                contact_solve(c, mB, iB, friction, cvx, cvy, cw);
+                                SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+                            }
+                        }
+                        mbox[0][lane] = cvx; mbox[1][lane] = cvy; mbox[2][lane] = cw;
                     }
+                    lds_sync();
                 }
+                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
             }
             // ---- StoreImpulses ----
 #pragma unroll

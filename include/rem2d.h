@@ -63,8 +63,9 @@ typedef struct {
  *   parent,ax..by,torque,lower,upper : world.CreateJoint(revoluteJointDef(bodyA, bodyB,
  *                           localAnchorA, localAnchorB, enableMotor, enableLimit, maxMotorTorque,
  *                           lowerAngle, upperAngle)) -- module_utility.py:19-32
- *   jround                : parallel round of the joint that preserves b2World::Solve's island
- *                           joint order (gym_rem2d_amd/compiler.py joint_rounds)
+ *   jround                : packed solver schedule derived from b2World::Solve's island joint order
+ *                           (gym_rem2d_amd/compiler.py joint_rounds / pipeline_schedule):
+ *                           bits 0-7 joint round, 8-15 contact slot, 16-23 pipeline period
  *   amp,phase,freq,offset,istate : node.controller -- Controller/m_controller.py:5-21 */
 typedef struct {
     const int32_t *shape; /* 0 none, 1 box, 2 circle */

@@ -151,7 +151,8 @@ def test_morphology_packing():
         assert m["parent"][lo] == -1
         for k, j in enumerate(s.joints):
             assert m["parent"][lo + j["child"]] == j["parent"] and j["child"] == k + 1
-            assert m["jround"][lo + j["child"]] == s.rounds[k]
+            assert (m["jround"][lo + j["child"]] & 0xff) == s.rounds[k]
+            assert (m["jround"][lo + j["child"]] >> 16) == s.period
     sub = m.take([4, 1])
     assert np.array_equal(sub["x"][:32], m["x"][4 * 32:5 * 32]) and np.array_equal(sub["amp"][32:], m["amp"][32:64])
     rep = Morphology.replicate(specs[0], 5)

@@ -21,7 +21,9 @@ for m in morphs:
     torch.cuda.synchronize()
     nb = m.n_bodies
     print("bucket lanes=%d envs=%d mean bodies %.1f" % (m.lanes, m.n_envs, nb.mean()))
-    jr = m["jround"].reshape(m.n_envs, m.lanes).max(1) + 1
+    jr = (m["jround"] & 0xff).reshape(m.n_envs, m.lanes).max(1) + 1
+    per = (m["jround"] >> 16).reshape(m.n_envs, m.lanes).max(1)
+    print(" pipeline period per creature: hist", np.bincount(per))
     print(" rounds per creature: mean %.1f max %d hist %s" % (jr.mean(), jr.max(), np.bincount(jr)))
     for (vi, pi) in ((180, 60), (0, 60), (180, 0), (0, 0), (180, 60)):
         torch.cuda.synchronize(); t0 = time.time()
