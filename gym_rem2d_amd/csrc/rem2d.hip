@@ -554,7 +554,7 @@ DEV void pairs_insert_front(const State &S, unsigned gl, int &count, int edge, i
         CF(C_T1, d) = CF(C_T1, f);
     }
     CI(C_EDGE, gl) = edge;
-    CI(C_INFO, gl) = 0;
+    CI(C_INFO, gl) = 1 << 16; // e_enabledFlag (CI_ENABLED)
     CU(C_KEY0, gl) = 0u;
     CU(C_KEY1, gl) = 0u;
     CF(C_N0, gl) = 0.0f;
@@ -789,9 +789,614 @@ DEV void cc_load(const State &S, unsigned cb, ContactC &c) {
 }
 
 // =====================================================================================
+// continuous collision: b2Distance (GJK), b2TimeOfImpact, and the per-body TOI event loop of
+// b2World::SolveTOI.  Body A is always a static terrain shape (identity transform, time-
+// transparent sweep), body B this lane's module, so every body's TOI sequence is independent.
+// =====================================================================================
+struct XF { V2 p; Rot q; };
+DEV V2 xfmul(const XF &T, V2 v) { return xmul(T.q, T.p, v); }
+DEV XF xf_identity() { XF T; T.p = mk(0.0f, 0.0f); T.q.s = 0.0f; T.q.c = 1.0f; return T; }
+
+struct Proxy { V2 v[4]; int count; float radius; };
+DEV V2 pget(const Proxy &p, int i) { return sel4(p.v, i); }
+DEV int psupport(const Proxy &p, V2 d) {
+    int best = 0;
+    float bv = vdot(p.v[0], d);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        if (i < p.count) {
+            float val = vdot(p.v[i], d);
+            if (val > bv) { best = i; bv = val; }
+        }
+    }
+    return best;
+}
+DEV Proxy proxy_edge(V2 a, V2 b) {
+    Proxy p; p.v[0] = a; p.v[1] = b; p.v[2] = mk(0.0f, 0.0f); p.v[3] = mk(0.0f, 0.0f); p.count = 2; p.radius = B2_POLYGON_RADIUS; return p;
+}
+DEV Proxy proxy_body(int shape, float hx, float hy) {
+    Proxy p;
+    if (shape == SHAPE_BOX) {
+        p.v[0] = mk(-hx, -hy); p.v[1] = mk(hx, -hy); p.v[2] = mk(hx, hy); p.v[3] = mk(-hx, hy); p.count = 4; p.radius = B2_POLYGON_RADIUS;
+    } else {
+        p.v[0] = mk(0.0f, 0.0f); p.v[1] = p.v[0]; p.v[2] = p.v[0]; p.v[3] = p.v[0]; p.count = 1; p.radius = hx;
+    }
+    return p;
+}
+struct SVtx { V2 wA, wB, w; float a; int iA, iB; };
+struct Simplex { SVtx v0, v1, v2; int count; };
+struct SCache { float metric; int count; int iA0, iA1, iA2, iB0, iB1, iB2; };
+
+DEV float simplex_metric(const Simplex &s) {
+    if (s.count == 2) return sqrtf(vdist2(s.v0.w, s.v1.w));
+    if (s.count == 3) return vcross(vsub(s.v1.w, s.v0.w), vsub(s.v2.w, s.v0.w));
+    return 0.0f;
+}
+DEV SVtx svtx_make(const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB, int iA, int iB, float a) {
+    SVtx v;
+    v.iA = iA; v.iB = iB;
+    v.wA = xfmul(xfA, pget(pA, iA));
+    v.wB = xfmul(xfB, pget(pB, iB));
+    v.w = vsub(v.wB, v.wA);
+    v.a = a;
+    return v;
+}
+DEV void simplex_read_cache(Simplex &s, const SCache &c, const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB) {
+    s.count = c.count;
+    s.v0 = svtx_make(pA, xfA, pB, xfB, c.count > 0 ? c.iA0 : 0, c.count > 0 ? c.iB0 : 0, 0.0f);
+    s.v1 = svtx_make(pA, xfA, pB, xfB, c.count > 1 ? c.iA1 : 0, c.count > 1 ? c.iB1 : 0, 0.0f);
+    s.v2 = svtx_make(pA, xfA, pB, xfB, c.count > 2 ? c.iA2 : 0, c.count > 2 ? c.iB2 : 0, 0.0f);
+    if (s.count > 1) {
+        float metric1 = c.metric;
+        float metric2 = simplex_metric(s);
+        if (metric2 < 0.5f * metric1 || 2.0f * metric1 < metric2 || metric2 < B2_EPSILON) s.count = 0;
+    }
+    if (s.count == 0) {
+        s.v0 = svtx_make(pA, xfA, pB, xfB, 0, 0, 1.0f);
+        s.count = 1;
+    }
+}
+DEV void simplex_write_cache(const Simplex &s, SCache &c) {
+    c.metric = simplex_metric(s);
+    c.count = s.count;
+    c.iA0 = s.v0.iA; c.iB0 = s.v0.iB;
+    c.iA1 = s.v1.iA; c.iB1 = s.v1.iB;
+    c.iA2 = s.v2.iA; c.iB2 = s.v2.iB;
+}
+DEV void simplex_solve2(Simplex &s) {
+    V2 w1 = s.v0.w, w2 = s.v1.w;
+    V2 e12 = vsub(w2, w1);
+    float d12_2 = -vdot(w1, e12);
+    if (d12_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
+    float d12_1 = vdot(w2, e12);
+    if (d12_1 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
+    float inv_d12 = 1.0f / (d12_1 + d12_2);
+    s.v0.a = d12_1 * inv_d12;
+    s.v1.a = d12_2 * inv_d12;
+    s.count = 2;
+}
+DEV void simplex_solve3(Simplex &s) {
+    V2 w1 = s.v0.w, w2 = s.v1.w, w3 = s.v2.w;
+    V2 e12 = vsub(w2, w1);
+    float w1e12 = vdot(w1, e12), w2e12 = vdot(w2, e12);
+    float d12_1 = w2e12, d12_2 = -w1e12;
+    V2 e13 = vsub(w3, w1);
+    float w1e13 = vdot(w1, e13), w3e13 = vdot(w3, e13);
+    float d13_1 = w3e13, d13_2 = -w1e13;
+    V2 e23 = vsub(w3, w2);
+    float w2e23 = vdot(w2, e23), w3e23 = vdot(w3, e23);
+    float d23_1 = w3e23, d23_2 = -w2e23;
+    float n123 = vcross(e12, e13);
+    float d123_1 = n123 * vcross(w2, w3);
+    float d123_2 = n123 * vcross(w3, w1);
+    float d123_3 = n123 * vcross(w1, w2);
+    if (d12_2 <= 0.0f && d13_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
+    if (d12_1 > 0.0f && d12_2 > 0.0f && d123_3 <= 0.0f) {
+        float inv_d12 = 1.0f / (d12_1 + d12_2);
+        s.v0.a = d12_1 * inv_d12; s.v1.a = d12_2 * inv_d12; s.count = 2; return;
+    }
+    if (d13_1 > 0.0f && d13_2 > 0.0f && d123_2 <= 0.0f) {
+        float inv_d13 = 1.0f / (d13_1 + d13_2);
+        s.v0.a = d13_1 * inv_d13; s.v2.a = d13_2 * inv_d13; s.count = 2; s.v1 = s.v2; return;
+    }
+    if (d12_1 <= 0.0f && d23_2 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
+    if (d13_1 <= 0.0f && d23_1 <= 0.0f) { s.v2.a = 1.0f; s.count = 1; s.v0 = s.v2; return; }
+    if (d23_1 > 0.0f && d23_2 > 0.0f && d123_1 <= 0.0f) {
+        float inv_d23 = 1.0f / (d23_1 + d23_2);
+        s.v1.a = d23_1 * inv_d23; s.v2.a = d23_2 * inv_d23; s.count = 2; s.v0 = s.v2; return;
+    }
+    float inv_d123 = 1.0f / (d123_1 + d123_2 + d123_3);
+    s.v0.a = d123_1 * inv_d123; s.v1.a = d123_2 * inv_d123; s.v2.a = d123_3 * inv_d123; s.count = 3;
+}
+// b2Distance with useRadii = false; returns the distance between the core shapes
+DEV float gjk_distance(SCache &cache, const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB) {
+    Simplex s;
+    simplex_read_cache(s, cache, pA, xfA, pB, xfB);
+    int iter = 0;
+    while (iter < 20) {
+        int saveCount = s.count;
+        int sA0 = s.v0.iA, sB0 = s.v0.iB, sA1 = s.v1.iA, sB1 = s.v1.iB, sA2 = s.v2.iA, sB2 = s.v2.iB;
+        if (s.count == 2) simplex_solve2(s);
+        else if (s.count == 3) simplex_solve3(s);
+        if (s.count == 3) break;
+        // search direction
+        V2 d;
+        if (s.count == 1) d = vneg(s.v0.w);
+        else {
+            V2 e12 = vsub(s.v1.w, s.v0.w);
+            float sgn = vcross(e12, vneg(s.v0.w));
+            d = sgn > 0.0f ? vcross_sv(1.0f, e12) : vcross_vs(e12, 1.0f);
+        }
+        if (vdot(d, d) < B2_EPSILON * B2_EPSILON) break;
+        int iA = psupport(pA, rmulT(xfA.q, vneg(d)));
+        int iB = psupport(pB, rmulT(xfB.q, d));
+        SVtx nv = svtx_make(pA, xfA, pB, xfB, iA, iB, 0.0f);
+        // vertices[count] = nv (a is left as it was in Box2D: stale; it is overwritten by the next Solve)
+        if (s.count == 1) { nv.a = s.v1.a; s.v1 = nv; } else { nv.a = s.v2.a; s.v2 = nv; }
+        ++iter;
+        bool duplicate = (saveCount > 0 && iA == sA0 && iB == sB0) || (saveCount > 1 && iA == sA1 && iB == sB1) ||
+                         (saveCount > 2 && iA == sA2 && iB == sB2);
+        if (duplicate) break;
+        ++s.count;
+    }
+    V2 pointA, pointB;
+    if (s.count == 1) { pointA = s.v0.wA; pointB = s.v0.wB; }
+    else if (s.count == 2) {
+        pointA = vadd(vscale(s.v0.a, s.v0.wA), vscale(s.v1.a, s.v1.wA));
+        pointB = vadd(vscale(s.v0.a, s.v0.wB), vscale(s.v1.a, s.v1.wB));
+    } else {
+        pointA = vadd(vadd(vscale(s.v0.a, s.v0.wA), vscale(s.v1.a, s.v1.wA)), vscale(s.v2.a, s.v2.wA));
+        pointB = pointA;
+    }
+    simplex_write_cache(s, cache);
+    return sqrtf(vdist2(pointA, pointB));
+}
+
+struct Sweep { V2 c0, c; float a0, a; };
+DEV XF sweep_xf(const Sweep &s, float beta) {
+    XF T;
+    T.p = vadd(vscale(1.0f - beta, s.c0), vscale(beta, s.c));
+    float angle = (1.0f - beta) * s.a0 + beta * s.a;
+    T.q = rot_set(angle);
+    T.p = vsub(T.p, rmul(T.q, mk(0.0f, 0.0f)));
+    return T;
+}
+enum { SEP_POINTS = 0, SEP_FACE_A = 1, SEP_FACE_B = 2 };
+struct SepFn { int type; V2 localPoint, axis; };
+DEV void sepfn_init(SepFn &f, const SCache &cache, const Proxy &pA, const Proxy &pB, const Sweep &sB, float t1) {
+    XF xfA = xf_identity(), xfB = sweep_xf(sB, t1);
+    f.localPoint = mk(0.0f, 0.0f);
+    if (cache.count == 1) {
+        f.type = SEP_POINTS;
+        V2 pointA = xfmul(xfA, pget(pA, cache.iA0)), pointB = xfmul(xfB, pget(pB, cache.iB0));
+        f.axis = vsub(pointB, pointA);
+        vnormalize(f.axis);
+    } else if (cache.iA0 == cache.iA1) {
+        f.type = SEP_FACE_B;
+        V2 lB1 = pget(pB, cache.iB0), lB2 = pget(pB, cache.iB1);
+        f.axis = vcross_vs(vsub(lB2, lB1), 1.0f);
+        vnormalize(f.axis);
+        V2 normal = rmul(xfB.q, f.axis);
+        f.localPoint = vscale(0.5f, vadd(lB1, lB2));
+        V2 pointB = xfmul(xfB, f.localPoint);
+        V2 pointA = xfmul(xfA, pget(pA, cache.iA0));
+        float s = vdot(vsub(pointA, pointB), normal);
+        if (s < 0.0f) f.axis = vneg(f.axis);
+    } else {
+        f.type = SEP_FACE_A;
+        V2 lA1 = pget(pA, cache.iA0), lA2 = pget(pA, cache.iA1);
+        f.axis = vcross_vs(vsub(lA2, lA1), 1.0f);
+        vnormalize(f.axis);
+        V2 normal = rmul(xfA.q, f.axis);
+        f.localPoint = vscale(0.5f, vadd(lA1, lA2));
+        V2 pointA = xfmul(xfA, f.localPoint);
+        V2 pointB = xfmul(xfB, pget(pB, cache.iB0));
+        float s = vdot(vsub(pointB, pointA), normal);
+        if (s < 0.0f) f.axis = vneg(f.axis);
+    }
+}
+DEV float sepfn_find_min(const SepFn &f, const Proxy &pA, const Proxy &pB, const Sweep &sB, int &indexA, int &indexB, float t) {
+    XF xfA = xf_identity(), xfB = sweep_xf(sB, t);
+    if (f.type == SEP_POINTS) {
+        V2 axisA = rmulT(xfA.q, f.axis);
+        V2 axisB = rmulT(xfB.q, vneg(f.axis));
+        indexA = psupport(pA, axisA);
+        indexB = psupport(pB, axisB);
+        V2 pointA = xfmul(xfA, pget(pA, indexA)), pointB = xfmul(xfB, pget(pB, indexB));
+        return vdot(vsub(pointB, pointA), f.axis);
+    } else if (f.type == SEP_FACE_A) {
+        V2 normal = rmul(xfA.q, f.axis);
+        V2 pointA = xfmul(xfA, f.localPoint);
+        V2 axisB = rmulT(xfB.q, vneg(normal));
+        indexA = -1;
+        indexB = psupport(pB, axisB);
+        V2 pointB = xfmul(xfB, pget(pB, indexB));
+        return vdot(vsub(pointB, pointA), normal);
+    } else {
+        V2 normal = rmul(xfB.q, f.axis);
+        V2 pointB = xfmul(xfB, f.localPoint);
+        V2 axisA = rmulT(xfA.q, vneg(normal));
+        indexB = -1;
+        indexA = psupport(pA, axisA);
+        V2 pointA = xfmul(xfA, pget(pA, indexA));
+        return vdot(vsub(pointA, pointB), normal);
+    }
+}
+DEV float sepfn_evaluate(const SepFn &f, const Proxy &pA, const Proxy &pB, const Sweep &sB, int indexA, int indexB, float t) {
+    XF xfA = xf_identity(), xfB = sweep_xf(sB, t);
+    if (f.type == SEP_POINTS) {
+        V2 pointA = xfmul(xfA, pget(pA, indexA)), pointB = xfmul(xfB, pget(pB, indexB));
+        return vdot(vsub(pointB, pointA), f.axis);
+    } else if (f.type == SEP_FACE_A) {
+        V2 normal = rmul(xfA.q, f.axis);
+        V2 pointA = xfmul(xfA, f.localPoint);
+        V2 pointB = xfmul(xfB, pget(pB, indexB));
+        return vdot(vsub(pointB, pointA), normal);
+    } else {
+        V2 normal = rmul(xfB.q, f.axis);
+        V2 pointB = xfmul(xfB, f.localPoint);
+        V2 pointA = xfmul(xfA, pget(pA, indexA));
+        return vdot(vsub(pointA, pointB), normal);
+    }
+}
+enum { TOI_UNKNOWN = 0, TOI_FAILED, TOI_OVERLAPPED, TOI_TOUCHING, TOI_SEPARATED };
+// b2TimeOfImpact(static A, swept B, tMax = 1)
+DEV void time_of_impact(int &state, float &tOut, const Proxy &pA, const Proxy &pB, Sweep sB) {
+    state = TOI_UNKNOWN;
+    const float tMax = 1.0f;
+    tOut = tMax;
+    { // b2Sweep::Normalize
+        float twoPi = 2.0f * B2_PI;
+        float d = twoPi * floorf(sB.a0 / twoPi);
+        sB.a0 -= d;
+        sB.a -= d;
+    }
+    float totalRadius = pA.radius + pB.radius;
+    float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
+    float tolerance = 0.25f * B2_LINEAR_SLOP;
+    float t1 = 0.0f;
+    int iter = 0;
+    SCache cache;
+    cache.metric = 0.0f; cache.count = 0; cache.iA0 = cache.iA1 = cache.iA2 = cache.iB0 = cache.iB1 = cache.iB2 = 0;
+    for (;;) {
+        XF xfA = xf_identity(), xfB = sweep_xf(sB, t1);
+        float distance = gjk_distance(cache, pA, xfA, pB, xfB);
+        if (distance <= 0.0f) { state = TOI_OVERLAPPED; tOut = 0.0f; break; }
+        if (distance < target + tolerance) { state = TOI_TOUCHING; tOut = t1; break; }
+        SepFn fcn;
+        sepfn_init(fcn, cache, pA, pB, sB, t1);
+        bool done = false;
+        float t2 = tMax;
+        int pushBackIter = 0;
+        for (;;) {
+            int indexA, indexB;
+            float s2 = sepfn_find_min(fcn, pA, pB, sB, indexA, indexB, t2);
+            if (s2 > target + tolerance) { state = TOI_SEPARATED; tOut = tMax; done = true; break; }
+            if (s2 > target - tolerance) { t1 = t2; break; }
+            float s1 = sepfn_evaluate(fcn, pA, pB, sB, indexA, indexB, t1);
+            if (s1 < target - tolerance) { state = TOI_FAILED; tOut = t1; done = true; break; }
+            if (s1 <= target + tolerance) { state = TOI_TOUCHING; tOut = t1; done = true; break; }
+            int rootIterCount = 0;
+            float a1 = t1, a2 = t2;
+            for (;;) {
+                float t;
+                if (rootIterCount & 1) t = a1 + (target - s1) * (a2 - a1) / (s2 - s1);
+                else t = 0.5f * (a1 + a2);
+                ++rootIterCount;
+                float s = sepfn_evaluate(fcn, pA, pB, sB, indexA, indexB, t);
+                if (fabs32(s - target) < tolerance) { t2 = t; break; }
+                if (s > target) { a1 = t; s1 = s; } else { a2 = t; s2 = s; }
+                if (rootIterCount == 50) break;
+            }
+            ++pushBackIter;
+            if (pushBackIter == 8) break;
+        }
+        ++iter;
+        if (done) break;
+        if (iter == 20) { state = TOI_FAILED; tOut = t1; break; }
+    }
+}
+
+// pair-slot info word: bits 0-7 manifold point count, 8-15 manifold type, then b2Contact flags
+#define CI_COUNT(i) ((i) & 0xff)
+#define CI_TYPE(i) (((i) >> 8) & 0xff)
+#define CI_ENABLED (1 << 16)
+#define CI_TOIFLAG (1 << 17)
+#define CI_ISLAND (1 << 18)
+#define CI_TOICOUNT_SHIFT 20
+#define CI_TOICOUNT(i) (((i) >> CI_TOICOUNT_SHIFT) & 0x1f)
+#define CI_KEEP_MASK (~0xffff) // flag bits survive a manifold update
+
+// b2Contact::Update for pair slot o32 of this lane at body transform (p, q): narrowphase, carry the
+// warm-start impulses over by feature id, store.  Returns the new manifold.
+DEV void contact_update_slot(const State &S, const Terrain &T, unsigned o, int shape, float hx, float hy, V2 p, Rot q,
+                             Manifold &m, bool sleepResetAlways, float &sleepT) {
+    int e = CI(C_EDGE, o);
+    V2 e1 = mk(T.v1x[e], T.v1y[e]), e2 = mk(T.v2x[e], T.v2y[e]);
+    if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, p, q);
+    else collide_edge_circle(m, e1, e2, hx, p);
+    int info = CI(C_INFO, o);
+    int oldCount = CI_COUNT(info);
+    if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed -> SetAwake
+    unsigned ok0 = CU(C_KEY0, o), ok1 = CU(C_KEY1, o);
+    float on0 = CF(C_N0, o), on1 = CF(C_N1, o), ot0 = CF(C_T0, o), ot1 = CF(C_T1, o);
+    float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
+    if (m.count > 0) {
+        if (oldCount > 0 && ok0 == m.k0) { n0 = on0; t0 = ot0; }
+        else if (oldCount > 1 && ok1 == m.k0) { n0 = on1; t0 = ot1; }
+    }
+    if (m.count > 1) {
+        if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
+        else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
+    }
+    CI(C_INFO, o) = (info & CI_KEEP_MASK) | CI_ENABLED | m.count | (m.type << 8);
+    CU(C_KEY0, o) = m.k0;
+    CU(C_KEY1, o) = m.k1;
+    CF(C_N0, o) = n0;
+    CF(C_N1, o) = n1;
+    CF(C_T0, o) = t0;
+    CF(C_T1, o) = t1;
+}
+DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
+    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
+    SW(sb, 0) = __int_as_float(m.type | (m.count << 8));
+    SW(sb, 1) = m.ln.x; SW(sb, 2) = m.ln.y; SW(sb, 3) = m.lp.x; SW(sb, 4) = m.lp.y;
+    SW(sb, 5) = m.p0.x; SW(sb, 6) = m.p0.y; SW(sb, 7) = m.p1.x; SW(sb, 8) = m.p1.y;
+}
+// scratch word offsets (per lane): manifolds [KT][SCR_WORDS], constraints [KT][CC_WORDS], TOI alphas [KC]
+#define SCR_CC_BASE (KT * SCR_WORDS)
+#define SCR_TOI_BASE (KT * SCR_WORDS + KT * CC_WORDS)
+#define SCR_SWEEP_BASE (SCR_TOI_BASE + KC) // c0.x, c0.y, a0 handed from the step kernel to the TOI kernel
+#define SCR_TOTAL_WORDS (SCR_SWEEP_BASE + 3)
+
+struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, events; };
+
+// b2World::SolveTOI restricted to this lane's body (see the section comment above).
+DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int shape, float hx, float hy, float mB, float iB,
+                                                float h, int velIters, float c0x, float c0y, float a0, LaneBody B) {
+    const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
+    const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
+    const float friction = T.friction;
+    const unsigned Lp = S.Lp;
+    // m_stepComplete is always true at this point: invalidate TOIs
+    float alpha0 = 0.0f;
+    Sweep sw;
+    sw.c0 = mk(c0x, c0y); sw.c = mk(B.px, B.py); sw.a0 = a0; sw.a = B.ang;
+    for (int s = 0; s < B.cCount; ++s) {
+        unsigned o = (unsigned)s * Lp + gl;
+        CI(C_INFO, o) = CI(C_INFO, o) & (0xffff | CI_ENABLED);
+    }
+    const Proxy pB = proxy_body(shape, hx, hy);
+    for (;;) {
+        int minSlot = -1;
+        float minAlpha = 1.0f;
+        for (int s = 0; s < B.cCount; ++s) {
+            unsigned o = (unsigned)s * Lp + gl;
+            int info = CI(C_INFO, o);
+            if (!(info & CI_ENABLED)) continue;
+            if (CI_TOICOUNT(info) > 8) continue;
+            float alpha = 1.0f;
+            if (info & CI_TOIFLAG) {
+                alpha = SW((unsigned)(SCR_TOI_BASE + s) * Lp + gl, 0);
+            } else {
+                if (!B.awake) continue;
+                int e = CI(C_EDGE, o);
+                Proxy pA = proxy_edge(mk(T.v1x[e], T.v1y[e]), mk(T.v2x[e], T.v2y[e]));
+                int state;
+                float t;
+                time_of_impact(state, t, pA, pB, sw);
+                float beta = t;
+                if (state == TOI_TOUCHING) alpha = fmin32(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+                else alpha = 1.0f;
+                SW((unsigned)(SCR_TOI_BASE + s) * Lp + gl, 0) = alpha;
+                CI(C_INFO, o) = info | CI_TOIFLAG;
+            }
+            if (alpha < minAlpha) { minSlot = s; minAlpha = alpha; }
+        }
+        if (minSlot < 0 || 1.0f - 10.0f * B2_EPSILON < minAlpha) break;
+        // ---- advance the body to the TOI (b2Body::Advance) ----
+        const Sweep backup = sw;
+        const float backupAlpha0 = alpha0;
+        {
+            float beta = (minAlpha - alpha0) / (1.0f - alpha0);
+            sw.c0 = vadd(sw.c0, vscale(beta, vsub(sw.c, sw.c0)));
+            sw.a0 += beta * (sw.a - sw.a0);
+            alpha0 = minAlpha;
+            sw.c = sw.c0;
+            sw.a = sw.a0;
+        }
+        Rot q = rot_set(sw.a);
+        V2 p = vsub(sw.c, rmul(q, mk(0.0f, 0.0f)));
+        const unsigned om = (unsigned)minSlot * Lp + gl;
+        Manifold m;
+        contact_update_slot(S, T, om, shape, hx, hy, p, q, m, sleepResetAlways, B.sleepT);
+        {
+            int info = CI(C_INFO, om);
+            int cnt = CI_TOICOUNT(info) + 1;
+            info = (info & ~(CI_TOIFLAG | (0x1f << CI_TOICOUNT_SHIFT))) | (cnt << CI_TOICOUNT_SHIFT);
+            if (m.count == 0) info &= ~CI_ENABLED; // not solid: SetEnabled(false), restore the sweep
+            CI(C_INFO, om) = info;
+        }
+        if (m.count == 0) {
+            sw = backup;
+            alpha0 = backupAlpha0;
+            continue;
+        }
+        if (sleepResetAlways || !B.awake) B.sleepT = 0.0f;
+        B.awake = 1;
+        B.events += 1;
+        // ---- TOI island: this body, the TOI contact, then its other touching contacts (list order) ----
+        int nIsl = 0;
+        unsigned islPack = 0u;
+        manifold_store(S, gl, 0, m);
+        islPack |= (unsigned)minSlot;
+        nIsl = 1;
+        CI(C_INFO, om) = CI(C_INFO, om) | CI_ISLAND;
+        for (int s = 0; s < B.cCount; ++s) {
+            if (s == minSlot) continue;
+            unsigned o = (unsigned)s * Lp + gl;
+            Manifold mo;
+            contact_update_slot(S, T, o, shape, hx, hy, p, q, mo, sleepResetAlways, B.sleepT);
+            if (mo.count == 0) continue;
+            if (nIsl >= KT) { B.err |= REM2D_ERR_SOLVER_OVERFLOW; continue; }
+            manifold_store(S, gl, nIsl, mo);
+            islPack |= (unsigned)s << (5 * nIsl);
+            ++nIsl;
+        }
+        // ---- b2Island::SolveTOI ----
+        float cx = sw.c.x, cy = sw.c.y, ca = sw.a;
+        for (int it = 0; it < 20; ++it) { // SolveTOIPositionConstraints: only this body moves
+            float minSeparation = 0.0f;
+            for (int t = 0; t < nIsl; ++t) {
+                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
+                int tc = __float_as_int(SW(sb, 0));
+                int mtype = tc & 0xff, mcount = tc >> 8;
+                V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
+                const float radiusA = B2_POLYGON_RADIUS;
+                for (int j = 0; j < mcount; ++j) {
+                    V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
+                    V2 cB = mk(cx, cy);
+                    V2 normal, point;
+                    float separation;
+                    Rot qB = rot_set(ca);
+                    if (mtype == MF_CIRCLES) {
+                        V2 pointA = lp;
+                        V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
+                        normal = vsub(pointB, pointA);
+                        vnormalize(normal);
+                        point = vscale(0.5f, vadd(pointA, pointB));
+                        separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
+                    } else if (mtype == MF_FACE_A) {
+                        normal = ln;
+                        V2 clipPoint = xmul(qB, cB, pj);
+                        separation = vdot(vsub(clipPoint, lp), normal) - radiusA - radiusB;
+                        point = clipPoint;
+                    } else {
+                        normal = rmul(qB, ln);
+                        V2 planePoint = xmul(qB, cB, lp);
+                        V2 clipPoint = pj;
+                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+                        point = clipPoint;
+                        normal = vneg(normal);
+                    }
+                    V2 rBp = vsub(point, cB);
+                    minSeparation = fmin32(minSeparation, separation);
+                    float C = fclamp(0.75f * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+                    float rnB = vcross(rBp, normal);
+                    float Kn = mB + iB * rnB * rnB;
+                    float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+                    V2 P = vscale(impulse, normal);
+                    cx = cx + mB * P.x;
+                    cy = cy + mB * P.y;
+                    ca += iB * vcross(rBp, P);
+                }
+            }
+            if (minSeparation >= -1.5f * B2_LINEAR_SLOP) break;
+        }
+        // leap of faith to the new safe state
+        sw.c0 = mk(cx, cy);
+        sw.a0 = ca;
+        // InitializeVelocityConstraints without warm starting, then velIters sweeps over the island contacts
+        {
+            Rot qn = rot_set(ca);
+            for (int t = 0; t < nIsl; ++t) {
+                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
+                int tc = __float_as_int(SW(sb, 0));
+                ContactC c;
+                contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)), mk(SW(sb, 5), SW(sb, 6)),
+                              mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
+                cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
+            }
+        }
+        for (int it = 0; it < velIters; ++it) {
+            for (int t = 0; t < nIsl; ++t) {
+                const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
+                ContactC c;
+                cc_load(S, cb, c);
+                contact_solve(c, mB, iB, friction, B.vx, B.vy, B.w);
+                SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+            }
+        }
+        // integrate the remaining (1 - minAlpha) * dt; TOI impulses are not stored
+        {
+            float hs = (1.0f - minAlpha) * h;
+            V2 v = mk(B.vx, B.vy);
+            V2 translation = vscale(hs, v);
+            if (vdot(translation, translation) > B2_MAX_TRANSLATION_SQ) {
+                float ratio = B2_MAX_TRANSLATION / vlen(translation);
+                v = vscale(ratio, v);
+            }
+            float rotation = hs * B.w;
+            if (rotation * rotation > B2_MAX_ROTATION_SQ) {
+                float ratio = B2_MAX_ROTATION / fabs32(rotation);
+                B.w *= ratio;
+            }
+            cx = cx + hs * v.x;
+            cy = cy + hs * v.y;
+            ca += hs * B.w;
+            B.vx = v.x; B.vy = v.y;
+        }
+        sw.c = mk(cx, cy);
+        sw.a = ca;
+        // ---- reset flags, SynchronizeFixtures, FindNewContacts ----
+        for (int s = 0; s < B.cCount; ++s) {
+            unsigned o = (unsigned)s * Lp + gl;
+            CI(C_INFO, o) = CI(C_INFO, o) & ~(CI_TOIFLAG | CI_ISLAND);
+        }
+        {
+            Rot q0 = rot_set(sw.a0), q1 = rot_set(sw.a);
+            V2 p0 = vsub(sw.c0, rmul(q0, mk(0.0f, 0.0f)));
+            V2 p1 = vsub(sw.c, rmul(q1, mk(0.0f, 0.0f)));
+            AABB b1 = body_aabb(shape, hx, hy, p0, q0), b2 = body_aabb(shape, hx, hy, p1, q1);
+            V2 lo = vmin2(b1.lo, b2.lo), hi = vmax2(b1.hi, b2.hi);
+            V2 displacement = vsub(p1, p0);
+            V2 fatLo = mk(LF(L_FATLX), LF(L_FATLY)), fatHi = mk(LF(L_FATUX), LF(L_FATUY));
+            bool contains = fatLo.x <= lo.x && fatLo.y <= lo.y && hi.x <= fatHi.x && hi.y <= fatHi.y;
+            if (!contains) {
+                V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
+                V2 flo = vsub(lo, r), fhi = vadd(hi, r);
+                V2 d = vscale(B2_AABB_MULTIPLIER, displacement);
+                if (d.x < 0.0f) flo.x += d.x; else fhi.x += d.x;
+                if (d.y < 0.0f) flo.y += d.y; else fhi.y += d.y;
+                LF(L_FATLX) = flo.x; LF(L_FATLY) = flo.y; LF(L_FATUX) = fhi.x; LF(L_FATUY) = fhi.y;
+                if (find_new_pairs(S, T, gl, B.cCount, flo, fhi, B.err)) {
+                    if (sleepResetAlways || !B.awake) B.sleepT = 0.0f;
+                    B.awake = 1;
+                }
+            }
+        }
+    }
+    B.px = sw.c.x; B.py = sw.c.y; B.ang = sw.a;
+    return B;
+}
+
+// wod / reward / done (Modular2DEnv.py:613-614,642-649) and evaluate()'s fitness rule
+// (REM2D_main.py:362-377); executed by one lane per creature, once per env step.
+DEV void env_bookkeeping(const State &S, unsigned env, int sub, float rootx) {
+    if (sub != 0) return;
+    double wod = ED(E_WOD) + 0.04;
+    ED(E_WOD) = wod;
+    double r = (double)rootx;
+    double rew = r;
+    int d = 0;
+    if (r < 0.0) { rew = -100.0; d = 1; }
+    if (wod > r) { rew = -100.0; d = 1; }
+    EF(E_REWARD) = (float)rew;
+    EI(E_DONE) = d;
+    if (d) EI(E_EVERDONE) = 1;
+    int stepIdx = EI(E_STEPS);
+    if (!EI(E_FROZEN)) {
+        if (rew < -10.0) EI(E_FROZEN) = 1;
+        else if (rew > 100.0) { ED(E_FITNESS) = rew + (double)(10000 - stepIdx) / 10000.0; EI(E_FROZEN) = 1; }
+        else if (rew > 0.0) ED(E_FITNESS) = rew;
+    }
+    EI(E_STEPS) = stepIdx + 1;
+}
+
+// =====================================================================================
 // the step kernel
 // =====================================================================================
-struct StepArgs { int nSteps; float dt; int velIters, posIters; };
+struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ };
 
 // Register budget: what the 180-iteration velocity loop touches stays in VGPRs (body velocity,
 // joint effective-mass terms and impulses, KR contact constraints); everything else (pose
@@ -861,6 +1466,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
             }
         }
         // =============== b2World::Step ===============
+        const float c0x = px, c0y = py, a0 = ang; // sweep start (b2Island::Solve: c0 = c, a0 = a)
         const float dtRatio = invDt0 * h;
         const float hx = LF(L_HX), hy = LF(L_HY);
         const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
@@ -888,42 +1494,10 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                     continue;
                 }
                 Manifold m;
-                V2 e1 = mk(T.v1x[e], T.v1y[e]), e2 = mk(T.v2x[e], T.v2y[e]);
-                if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, mk(px, py), q);
-                else collide_edge_circle(m, e1, e2, hx, mk(px, py));
-                // b2Contact::Update: carry impulses over by feature id
-                int oldCount = CI(C_INFO, o) & 0xff;
-                if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed
-                unsigned ok0 = CU(C_KEY0, o), ok1 = CU(C_KEY1, o);
-                float on0 = CF(C_N0, o), on1 = CF(C_N1, o), ot0 = CF(C_T0, o), ot1 = CF(C_T1, o);
-                float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
-                if (m.count > 0) {
-                    if (oldCount > 0 && ok0 == m.k0) { n0 = on0; t0 = ot0; }
-                    else if (oldCount > 1 && ok1 == m.k0) { n0 = on1; t0 = ot1; }
-                }
-                if (m.count > 1) {
-                    if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
-                    else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
-                }
-                CI(C_INFO, o) = m.count | (m.type << 8);
-                CU(C_KEY0, o) = m.k0;
-                CU(C_KEY1, o) = m.k1;
-                CF(C_N0, o) = n0;
-                CF(C_N1, o) = n1;
-                CF(C_T0, o) = t0;
-                CF(C_T1, o) = t1;
+                contact_update_slot(S, T, o, shape, hx, hy, mk(px, py), q, m, sleepResetAlways, sleepT);
                 if (m.count > 0) {
                     if (nTouch < KT) {
-                        const unsigned sb = (unsigned)(nTouch * SCR_WORDS) * S.Lp + gl;
-                        SW(sb, 0) = __int_as_float(m.type | (m.count << 8));
-                        SW(sb, 1) = m.ln.x;
-                        SW(sb, 2) = m.ln.y;
-                        SW(sb, 3) = m.lp.x;
-                        SW(sb, 4) = m.lp.y;
-                        SW(sb, 5) = m.p0.x;
-                        SW(sb, 6) = m.p0.y;
-                        SW(sb, 7) = m.p1.x;
-                        SW(sb, 8) = m.p1.y;
+                        manifold_store(S, gl, nTouch, m);
                         slotPack |= (unsigned)s << (5 * nTouch);
                         ++nTouch;
                     } else {
@@ -1167,7 +1741,6 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                 }
             }
             // ---- integrate positions ----
-            const float c0x = px, c0y = py, a0 = ang;
             if (active) {
                 V2 v = mk(vx, vy);
                 V2 translation = vscale(h, v);
@@ -1349,30 +1922,12 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
                 }
             }
         }
-        if (h > 0.0f) invDt0 = inv_dt;
-        // =============== wod / reward / done / evaluate() fitness (one lane per creature) ===============
-        {
-            float rootx = __shfl(px, base);
-            if (sub == 0) {
-                double wod = ED(E_WOD) + 0.04;
-                ED(E_WOD) = wod;
-                double r = (double)rootx;
-                double rew = r;
-                int d = 0;
-                if (r < 0.0) { rew = -100.0; d = 1; }
-                if (wod > r) { rew = -100.0; d = 1; }
-                EF(E_REWARD) = (float)rew;
-                EI(E_DONE) = d;
-                if (d) EI(E_EVERDONE) = 1;
-                int stepIdx = EI(E_STEPS);
-                if (!EI(E_FROZEN)) {
-                    if (rew < -10.0) EI(E_FROZEN) = 1;
-                    else if (rew > 100.0) { ED(E_FITNESS) = rew + (double)(10000 - stepIdx) / 10000.0; EI(E_FROZEN) = 1; }
-                    else if (rew > 0.0) ED(E_FITNESS) = rew;
-                }
-                EI(E_STEPS) = stepIdx + 1;
-            }
+        if (A.defer) { // continuous physics: the TOI kernel needs the sweep start and finishes the step
+            const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
+            SW(wb, 0) = c0x; SW(wb, 1) = c0y; SW(wb, 2) = a0;
         }
+        if (h > 0.0f) invDt0 = inv_dt;
+        if (!A.defer) env_bookkeeping(S, env, sub, __shfl(px, base));
     }
     // ---- store ----
     gl = gl0; env = env0;
@@ -1386,6 +1941,37 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
         EF(E_INVDT0) = invDt0;
         EI(E_NEWFIX) = newFix; EI(E_ERR) = EI(E_ERR) | envErr; EI(E_POSITERS) = lastPosIters;
     }
+}
+
+// =====================================================================================
+// TOI kernel: b2World::SolveTOI for every lane, then the per-step bookkeeping.  Launched after
+// rem2d_step_kernel (nSteps = 1, defer = 1) when REM2D_FLAG_CONTINUOUS is set; kept out of the
+// step kernel so that its branchy GJK / root-finder code does not share a register allocation
+// with the velocity loop.
+// =====================================================================================
+template <int K>
+__global__ __launch_bounds__(WAVE) void rem2d_toi_kernel(State S, Terrain T, StepArgs A) {
+    const int lane = threadIdx.x;
+    const unsigned gl = blockIdx.x * WAVE + lane;
+    const unsigned env = gl / K;
+    const int base = lane & ~(K - 1);
+    const int sub = lane & (K - 1);
+    const int shape = LI(L_SHAPE);
+    float px = LF(L_PX);
+    if (shape != SHAPE_NONE && A.dt > 0.0f) {
+        const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
+        LaneBody B;
+        B.px = px; B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
+        B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
+        B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
+                           SW(wb, 2), B);
+        LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
+        LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
+        if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
+        if (B.err) atomicOr(&EI(E_ERR), B.err);
+        px = B.px;
+    }
+    env_bookkeeping(S, env, sub, __shfl(px, base));
 }
 
 // =====================================================================================
@@ -1556,13 +2142,11 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     if (!out) return fail(REM2D_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!cfg_ok(cfg)) return fail(REM2D_E_INVALID, "cfg: n_envs must be > 0 and lanes one of 2,4,8,16,32");
-    if (cfg->flags & REM2D_FLAG_CONTINUOUS)
-        return fail(REM2D_E_INVALID, "REM2D_FLAG_CONTINUOUS (SolveTOI) is not implemented on the HIP path yet");
     Layout L = make_layout(cfg);
     if (!state_dev || state_bytes < L.total) return fail(REM2D_E_INVALID, "state buffer missing or too small");
     // 32-bit per-lane byte offsets: (slots * Lp + lane) * 4 and (scratch words * Lp + lane) * 4 must fit
-    if ((size_t)L.Lp * (KT * SCR_WORDS + (KT - KR) * 21 + 1) * 4 >= ((size_t)1 << 32))
-        return fail(REM2D_E_INVALID, "too many lanes for one world (n_envs * lanes must stay below ~9 million)");
+    if ((size_t)L.Lp * (SCR_TOTAL_WORDS + 1) * 4 >= ((size_t)1 << 32))
+        return fail(REM2D_E_INVALID, "too many lanes for one world (n_envs * lanes must stay below ~5 million)");
     if (((uintptr_t)state_dev & 255) != 0) return fail(REM2D_E_INVALID, "state buffer must be 256-byte aligned");
     HIP_TRY(hipSetDevice(cfg->device));
     rem2d_world *w = new (std::nothrow) rem2d_world();
@@ -1577,7 +2161,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->launches = 0;
     bind_state(w);
     w->S.scr = nullptr;
-    hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)KT * SCR_WORDS + (size_t)(KT - KR) * 21) * L.Lp * sizeof(float));
+    hipError_t e = hipMalloc((void **)&w->S.scr, (size_t)SCR_TOTAL_WORDS * L.Lp * sizeof(float));
     if (e != hipSuccess) {
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
@@ -1675,11 +2259,13 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
+    const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     StepArgs A;
-    A.nSteps = n_steps;
+    A.nSteps = continuous ? 1 : n_steps;
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
+    A.defer = continuous ? 1 : 0;
     dim3 grid((unsigned)w->L.Lp / WAVE), block(WAVE);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1688,12 +2274,24 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    switch (w->cfg.lanes) {
-    case 2: hipLaunchKernelGGL(rem2d_step_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
-    case 4: hipLaunchKernelGGL(rem2d_step_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
-    case 8: hipLaunchKernelGGL(rem2d_step_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
-    case 16: hipLaunchKernelGGL(rem2d_step_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
-    default: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+    const int launches = continuous ? n_steps : 1;
+    for (int l = 0; l < launches; ++l) {
+        switch (w->cfg.lanes) {
+        case 2: hipLaunchKernelGGL(rem2d_step_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
+        case 4: hipLaunchKernelGGL(rem2d_step_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
+        case 8: hipLaunchKernelGGL(rem2d_step_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
+        case 16: hipLaunchKernelGGL(rem2d_step_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
+        default: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+        }
+        if (continuous) {
+            switch (w->cfg.lanes) {
+            case 2: hipLaunchKernelGGL(rem2d_toi_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
+            case 4: hipLaunchKernelGGL(rem2d_toi_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
+            case 8: hipLaunchKernelGGL(rem2d_toi_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
+            case 16: hipLaunchKernelGGL(rem2d_toi_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
+            default: hipLaunchKernelGGL(rem2d_toi_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+            }
+        }
     }
     HIP_TRY(hipGetLastError());
     if (w->timing) {

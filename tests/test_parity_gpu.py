@@ -98,7 +98,7 @@ def test_contact_and_joint_indices_bit_exact(gpu, oracle, rough_terrain):
                     n = oc[k][1]
                     assert (cinfo[k, e, s] & 0xff) == n                    # manifold point count
                     if n > 0:
-                        assert (cinfo[k, e, s] >> 8) == oc[k][2]           # manifold type
+                        assert ((cinfo[k, e, s] >> 8) & 0xff) == oc[k][2]  # manifold type
                     for j in range(n):
                         assert (int(key[j][k, e, s]) & 0xffffffff) == (int(oc[k][4 + j]) & 0xffffffff)
                         assert imp[j][k, e, s] == of[k][j] and imp[2 + j][k, e, s] == of[k][2 + j]
@@ -108,6 +108,30 @@ def test_contact_and_joint_indices_bit_exact(gpu, oracle, rough_terrain):
                     assert jst[q][e, s] == oj[b][q]
                 assert jlim[e, s] == int(oj[b][5])
         w.close()
+
+
+@pytest.mark.parametrize("name", ["chain4_left", "chain8_top", "lsystem_k32", "direct", "pairs_k2"])
+def test_continuous_physics_bit_exact(gpu, oracle, rough_terrain, name):
+    """b2World::SolveTOI (continuousPhysics, the pybox2d default): TOI search per pair (b2TimeOfImpact
+    / b2Distance), TOI sub-steps with their own position + 180-iteration velocity solve."""
+    from gym_rem2d_amd import _lib
+    morph = _populations()[name]
+    chunks = [1, 2, 7, 40, 150]
+    T = sum(chunks)
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), T, n_threads=8, trace=True,
+                           flags=oracle.FLAG_CONTINUOUS)
+    w, snaps = _run_gpu(gpu, morph, rough_terrain, chunks, _lib.FLAG_CONTINUOUS)
+    t = 0
+    for c, s in zip(chunks, snaps):
+        t += c
+        assert np.array_equal(s[..., :3], ref["trace"][t - 1]), "pose mismatch at step %d" % t
+    assert np.array_equal(snaps[-1], ref["bodies"])
+    assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+    assert int(w.view("err").max()) == 0
+    assert int(w.view("toievents").sum()) > 0  # landings do trigger TOI sub-steps
+    disc = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), T, n_threads=8)
+    assert not np.array_equal(disc["bodies"], ref["bodies"])  # and they change the outcome
+    w.close()
 
 
 def test_multi_step_launch_equals_single_steps(gpu, rough_terrain):
