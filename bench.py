@@ -60,7 +60,7 @@ def build_population(workload, n_envs, rank):
                     "bucketed by lane count %s and sorted by joint rounds" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
 
 
-def cpu_baseline(morphs, terrain, budget_s=12.0):
+def cpu_baseline(morphs, terrain, budget_s=12.0, flags=0):
     """The oracle (C restatement, OpenMP over creatures) on a bounded sample of the same workload."""
     from oracle import oracle as O
     O.build()
@@ -77,7 +77,7 @@ def cpu_baseline(morphs, terrain, budget_s=12.0):
     n = sum(s.n_envs for s in subs)
     while True:
         for s in subs:
-            O.batch_run(ot, s.as_dict(), steps, n_threads=cores)
+            O.batch_run(ot, s.as_dict(), steps, n_threads=cores, flags=flags)
         done_steps += steps
         if time.time() - t0 > budget_s or done_steps >= 2000:
             break
@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--discrete", action="store_true",
+                    help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +120,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    env = BatchedModular2D(flat=True, seed=4, device=dev)
+    from gym_rem2d_amd import _lib
+    env = BatchedModular2D(flat=True, seed=4, device=dev, flags=0 if args.discrete else _lib.FLAG_CONTINUOUS)
     batches, lo = [], 0
     for m in morphs:
         batches.append((m, list(range(lo, lo + m.n_envs))))
@@ -188,6 +191,7 @@ def main():
             "config": {"workload": workload_desc, "envs_per_gpu": n_envs, "steps_per_launch": spl,
                        "settle_steps": args.settle,
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,
+                       "continuous_physics": not args.discrete,
                        "parallelism": "population sharded over %d GPU(s), no per-step collective" % world,
                        "solver_errors": err},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -199,7 +203,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             from gym_rem2d_amd import make_terrain as _mt
-            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=True))
+            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=True), flags=0 if args.discrete else 1)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

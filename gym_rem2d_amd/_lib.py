@@ -71,6 +71,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
+    # Import torch first so that librem2d.so binds to the runtime torch initialises -- two runtimes
+    # in one process fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise Rem2dError(
             "gym_rem2d_amd: %s is missing -- the HIP extension is required (there is no CPU fallback). "

@@ -49,8 +49,11 @@ class WallOfDeath:
 
 
 class BatchedModular2D:
-    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=0):
-        self.hardcore, self.flat, self.flags = hardcore, flat, flags
+    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None):
+        # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
+        from . import _lib
+        self.hardcore, self.flat = hardcore, flat
+        self.flags = _lib.FLAG_CONTINUOUS if flags is None else flags
         self.device = device
         self._seed = seed
         self.terrain = None

@@ -45,7 +45,8 @@ def test_modular2d_facade_matches_oracle(need_gpu, oracle, rough_terrain):
     assert len(env.robot.joints) == len(env.robot.components) - 1
     t2 = copy.deepcopy(tree)
     spec, _, _ = build_creature(t2.getNodes(), ind.genome.moduleList)
-    ow = oracle.World.from_morph(oracle_terrain(oracle, rough_terrain), Morphology.from_specs([spec]).as_dict(), 0)
+    ow = oracle.World.from_morph(oracle_terrain(oracle, rough_terrain), Morphology.from_specs([spec]).as_dict(), 0,
+                                 flags=oracle.FLAG_CONTINUOUS)  # pybox2d default: continuousPhysics on
     for k in range(150):
         obs, reward, done, info = env.step(np.ones(4))
         r, d = ow.env_step()
@@ -72,7 +73,7 @@ def test_evaluate_and_population(need_gpu, oracle, rough_terrain):
         t = copy.deepcopy(ind.genome.create(8))
         specs.append(build_creature(t.getNodes(), ind.genome.moduleList)[0])
     ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), Morphology.from_specs(specs, 32).as_dict(), 2500,
-                           n_threads=8)["fitness"]
+                           n_threads=8, flags=oracle.FLAG_CONTINUOUS)["fitness"]
     fit = evaluate_population(inds)
     assert fit == ref.tolist()
     assert evaluate(inds[3]) == ref[3]
