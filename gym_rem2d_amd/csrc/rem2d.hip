@@ -128,14 +128,15 @@ static void field_place(const Layout &L, int f, size_t *off, size_t *count, int 
     if (dtype) *dtype = d.dtype;
 }
 
-struct Terrain {
+struct Terrain { // static bodies at the origin, in creation (= broadphase proxy) order: hardcore boxes, then edges
     int nEdge, nPoly;
-    const float *v1x, *v1y, *v2x, *v2y; // edge end points (world frame; terrain bodies sit at the origin)
-    const float *flx, *fly, *fux, *fuy; // fat AABB of every edge proxy
+    const float *flx, *fly, *fux, *fuy; // fat AABB of every static proxy            [nPoly + nEdge]
+    const float *vx, *vy;               // vertices [4][nPoly + nEdge] (edges use 0 and 1)
+    const float *nx, *ny;               // polygon normals [4][nPoly + nEdge]
+    int nStatic;
     float x0, invPitch;
     float friction; // b2MixFriction(terrain, module)
 };
-
 struct State {
     char *lane4, *lane8, *slot4, *env4, *env8; // group bases inside the caller's arena
     float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
@@ -494,6 +495,173 @@ DEV void collide_edge_box(Manifold &m, V2 v1, V2 v2, float hx, float hy, V2 p, R
     m.count = pointCount;
 }
 
+// ---- hardcore terrain: static convex boxes (b2CollidePolygons, b2CollidePolygonAndCircle) ----
+DEV V2 static_vert(const Terrain &T, int s, int k) { return mk(T.vx[k * T.nStatic + s], T.vy[k * T.nStatic + s]); }
+DEV V2 static_normal(const Terrain &T, int s, int k) { return mk(T.nx[k * T.nStatic + s], T.ny[k * T.nStatic + s]); }
+struct Poly4 { V2 v[4]; V2 n[4]; };
+struct XFq { V2 p; Rot q; };
+DEV V2 xq_mul(const XFq &T, V2 v) { return xmul(T.q, T.p, v); }
+DEV V2 xq_mulT(const XFq &T, V2 v) { return xmulT(T.q, T.p, v); }
+DEV XFq xq_mulT_xf(const XFq &A, const XFq &B) { // b2MulT(A, B)
+    XFq C;
+    C.q.s = A.q.c * B.q.s - A.q.s * B.q.c;
+    C.q.c = A.q.c * B.q.c + A.q.s * B.q.s;
+    C.p = rmulT(A.q, vsub(B.p, A.p));
+    return C;
+}
+// b2FindMaxSeparation (2.3.1, exhaustive)
+DEV float find_max_separation(int &edgeIndex, const Poly4 &poly1, const XFq &xf1, const Poly4 &poly2, const XFq &xf2) {
+    XFq xf = xq_mulT_xf(xf2, xf1);
+    int bestIndex = 0;
+    float maxSeparation = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V2 n = rmul(xf.q, poly1.n[i]);
+        V2 v1 = xq_mul(xf, poly1.v[i]);
+        float si = FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sij = vdot(n, vsub(poly2.v[j], v1));
+            if (sij < si) si = sij;
+        }
+        if (si > maxSeparation) { maxSeparation = si; bestIndex = i; }
+    }
+    edgeIndex = bestIndex;
+    return maxSeparation;
+}
+// b2CollidePolygons(static box A at identity, module box B); flip rule of 2.3.1
+DEV void collide_polygons(Manifold &m, const Poly4 &polyA, const Poly4 &polyB, V2 pB, Rot qB) {
+    m.count = 0;
+    m.type = MF_FACE_A;
+    m.ln = mk(0.0f, 0.0f); m.lp = mk(0.0f, 0.0f); m.p0 = mk(0.0f, 0.0f); m.p1 = mk(0.0f, 0.0f);
+    m.k0 = m.k1 = 0u;
+    XFq xfA; xfA.p = mk(0.0f, 0.0f); xfA.q.s = 0.0f; xfA.q.c = 1.0f;
+    XFq xfB; xfB.p = pB; xfB.q = qB;
+    const float totalRadius = B2_POLYGON_RADIUS + B2_POLYGON_RADIUS;
+    int edgeA = 0;
+    float separationA = find_max_separation(edgeA, polyA, xfA, polyB, xfB);
+    if (separationA > totalRadius) return;
+    int edgeB = 0;
+    float separationB = find_max_separation(edgeB, polyB, xfB, polyA, xfA);
+    if (separationB > totalRadius) return;
+    const float k_tol = 0.1f * B2_LINEAR_SLOP;
+    const bool flip = separationB > separationA + k_tol;
+    const Poly4 &poly1 = flip ? polyB : polyA;
+    const Poly4 &poly2 = flip ? polyA : polyB;
+    const XFq xf1 = flip ? xfB : xfA, xf2 = flip ? xfA : xfB;
+    const int edge1 = flip ? edgeB : edgeA;
+    m.type = flip ? MF_FACE_B : MF_FACE_A;
+    // b2FindIncidentEdge
+    ClipV incident[2];
+    {
+        V2 normal1 = rmulT(xf2.q, rmul(xf1.q, sel4(poly1.n, edge1)));
+        int index = 0;
+        float minDot = FLT_MAX;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float dot = vdot(normal1, poly2.n[i]);
+            if (dot < minDot) { minDot = dot; index = i; }
+        }
+        int i1 = index, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
+        incident[0].v = xq_mul(xf2, sel4(poly2.v, i1)); incident[0].iA = edge1; incident[0].iB = i1; incident[0].tA = CF_FACE; incident[0].tB = CF_VERTEX;
+        incident[1].v = xq_mul(xf2, sel4(poly2.v, i2)); incident[1].iA = edge1; incident[1].iB = i2; incident[1].tA = CF_FACE; incident[1].tB = CF_VERTEX;
+    }
+    int iv1 = edge1, iv2 = edge1 + 1 < 4 ? edge1 + 1 : 0;
+    V2 v11 = sel4(poly1.v, iv1), v12 = sel4(poly1.v, iv2);
+    V2 localTangent = vsub(v12, v11);
+    vnormalize(localTangent);
+    V2 localNormal = vcross_vs(localTangent, 1.0f);
+    V2 planePoint = vscale(0.5f, vadd(v11, v12));
+    V2 tangent = rmul(xf1.q, localTangent);
+    V2 normal = vcross_vs(tangent, 1.0f);
+    v11 = xq_mul(xf1, v11);
+    v12 = xq_mul(xf1, v12);
+    float frontOffset = vdot(normal, v11);
+    float sideOffset1 = -vdot(tangent, v11) + totalRadius;
+    float sideOffset2 = vdot(tangent, v12) + totalRadius;
+    ClipV c1[2], c2[2];
+    int np = clip_segment(c1, incident, vneg(tangent), sideOffset1, iv1);
+    if (np < 2) return;
+    np = clip_segment(c2, c1, tangent, sideOffset2, iv2);
+    if (np < 2) return;
+    m.ln = localNormal;
+    m.lp = planePoint;
+    int pointCount = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float separation = vdot(normal, c2[i].v) - frontOffset;
+        if (separation <= totalRadius) {
+            V2 lp = xq_mulT(xf2, c2[i].v);
+            unsigned key = flip ? mkkey(c2[i].iB, c2[i].iA, c2[i].tB, c2[i].tA) : mkkey(c2[i].iA, c2[i].iB, c2[i].tA, c2[i].tB);
+            if (pointCount == 0) { m.p0 = lp; m.k0 = key; }
+            else { m.p1 = lp; m.k1 = key; }
+            ++pointCount;
+        }
+    }
+    m.count = pointCount;
+}
+// b2CollidePolygonAndCircle(static box A at identity, circle B with m_p = 0)
+DEV void collide_polygon_circle(Manifold &m, const Poly4 &polyA, float rB, V2 center) {
+    m.count = 0;
+    m.type = MF_FACE_A;
+    m.ln = mk(0.0f, 0.0f); m.lp = mk(0.0f, 0.0f); m.p0 = mk(0.0f, 0.0f); m.p1 = mk(0.0f, 0.0f);
+    m.k0 = m.k1 = 0u;
+    V2 cLocal = center;
+    int normalIndex = 0;
+    float separation = -FLT_MAX;
+    float radius = B2_POLYGON_RADIUS + rB;
+    bool out = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float s = vdot(polyA.n[i], vsub(cLocal, polyA.v[i]));
+        if (s > radius) out = true;
+        if (!out && s > separation) { separation = s; normalIndex = i; }
+    }
+    if (out) return;
+    int vertIndex1 = normalIndex, vertIndex2 = vertIndex1 + 1 < 4 ? vertIndex1 + 1 : 0;
+    V2 v1 = sel4(polyA.v, vertIndex1), v2 = sel4(polyA.v, vertIndex2);
+    if (separation < B2_EPSILON) {
+        m.count = 1;
+        m.ln = sel4(polyA.n, normalIndex);
+        m.lp = vscale(0.5f, vadd(v1, v2));
+        return;
+    }
+    float u1 = vdot(vsub(cLocal, v1), vsub(v2, v1));
+    float u2 = vdot(vsub(cLocal, v2), vsub(v1, v2));
+    if (u1 <= 0.0f) {
+        if (vdist2(cLocal, v1) > radius * radius) return;
+        m.count = 1;
+        m.ln = vsub(cLocal, v1);
+        vnormalize(m.ln);
+        m.lp = v1;
+    } else if (u2 <= 0.0f) {
+        if (vdist2(cLocal, v2) > radius * radius) return;
+        m.count = 1;
+        m.ln = vsub(cLocal, v2);
+        vnormalize(m.ln);
+        m.lp = v2;
+    } else {
+        V2 faceCenter = vscale(0.5f, vadd(v1, v2));
+        float sep = vdot(vsub(cLocal, faceCenter), sel4(polyA.n, vertIndex1));
+        if (sep > radius) return;
+        m.count = 1;
+        m.ln = sel4(polyA.n, vertIndex1);
+        m.lp = faceCenter;
+    }
+}
+DEV Poly4 static_poly(const Terrain &T, int s) {
+    Poly4 P;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { P.v[k] = static_vert(T, s, k); P.n[k] = static_normal(T, s, k); }
+    return P;
+}
+DEV Poly4 box_poly(float hx, float hy) {
+    Poly4 P;
+    P.v[0] = mk(-hx, -hy); P.v[1] = mk(hx, -hy); P.v[2] = mk(hx, hy); P.v[3] = mk(-hx, hy);
+    P.n[0] = mk(0.0f, -1.0f); P.n[1] = mk(1.0f, 0.0f); P.n[2] = mk(0.0f, 1.0f); P.n[3] = mk(-1.0f, 0.0f);
+    return P;
+}
+
 // =====================================================================================
 // shape AABBs (b2PolygonShape/b2CircleShape::ComputeAABB)
 // =====================================================================================
@@ -581,16 +749,26 @@ DEV void pairs_remove(const State &S, unsigned gl, int &count, int s) {
 // b2BroadPhase::UpdatePairs for one moved body proxy: new pairs in ascending edge (= proxy id) order
 DEV bool find_new_pairs(const State &S, const Terrain &T, unsigned gl, int &count, V2 flo, V2 fhi, int &err) {
     bool added = false;
+    for (int st = 0; st < T.nPoly; ++st) { // hardcore boxes have the lowest proxy ids
+        if (!aabb_overlap(mk(T.flx[st], T.fly[st]), mk(T.fux[st], T.fuy[st]), flo, fhi)) continue;
+        bool exists = false;
+        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == st);
+        if (!exists) {
+            pairs_insert_front(S, gl, count, st, err);
+            added = true;
+        }
+    }
     int lo = (int)floorf((flo.x - 0.25f - T.x0) * T.invPitch) - 1;
     int hi = (int)floorf((fhi.x + 0.25f - T.x0) * T.invPitch) + 1;
     lo = lo < 0 ? 0 : lo;
     hi = hi > T.nEdge - 1 ? T.nEdge - 1 : hi;
     for (int e = lo; e <= hi; ++e) {
-        if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), flo, fhi)) continue;
+        const int st = T.nPoly + e;
+        if (!aabb_overlap(mk(T.flx[st], T.fly[st]), mk(T.fux[st], T.fuy[st]), flo, fhi)) continue;
         bool exists = false;
-        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == e);
+        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == st);
         if (!exists) {
-            pairs_insert_front(S, gl, count, e, err);
+            pairs_insert_front(S, gl, count, st, err);
             added = true; // b2ContactManager::AddPair wakes both bodies
         }
     }
@@ -1111,10 +1289,16 @@ DEV void time_of_impact(int &state, float &tOut, const Proxy &pA, const Proxy &p
 // warm-start impulses over by feature id, store.  Returns the new manifold.
 DEV void contact_update_slot(const State &S, const Terrain &T, unsigned o, int shape, float hx, float hy, V2 p, Rot q,
                              Manifold &m, bool sleepResetAlways, float &sleepT) {
-    int e = CI(C_EDGE, o);
-    V2 e1 = mk(T.v1x[e], T.v1y[e]), e2 = mk(T.v2x[e], T.v2y[e]);
-    if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, p, q);
-    else collide_edge_circle(m, e1, e2, hx, p);
+    int e = CI(C_EDGE, o); // static proxy index: hardcore boxes first, then edges
+    if (e < T.nPoly) {
+        Poly4 PA = static_poly(T, e);
+        if (shape == SHAPE_BOX) collide_polygons(m, PA, box_poly(hx, hy), p, q);
+        else collide_polygon_circle(m, PA, hx, p);
+    } else {
+        V2 e1 = static_vert(T, e, 0), e2 = static_vert(T, e, 1);
+        if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, p, q);
+        else collide_edge_circle(m, e1, e2, hx, p);
+    }
     int info = CI(C_INFO, o);
     int oldCount = CI_COUNT(info);
     if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed -> SetAwake
@@ -1181,7 +1365,8 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             } else {
                 if (!B.awake) continue;
                 int e = CI(C_EDGE, o);
-                Proxy pA = proxy_edge(mk(T.v1x[e], T.v1y[e]), mk(T.v2x[e], T.v2y[e]));
+                Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
+                if (e < T.nPoly) { pA.v[2] = static_vert(T, e, 2); pA.v[3] = static_vert(T, e, 3); pA.count = 4; }
                 int state;
                 float t;
                 time_of_impact(state, t, pA, pB, sw);
@@ -2193,38 +2378,99 @@ extern "C" int rem2d_world_destroy(rem2d_world *w) {
     return REM2D_OK;
 }
 
+// b2PolygonShape::Set for one hardcore box (2.3.1): weld, gift-wrap hull from the right-most (lowest)
+// point, counter-clockwise, edge normals.  Host arithmetic in binary32, no FMA (-ffp-contract=off).
+static bool host_poly_set(const float *xy /*[4][2]*/, float vx[4], float vy[4], float nx[4], float ny[4]) {
+    float px[4], py[4];
+    int n = 0;
+    for (int i = 0; i < 4; ++i) {
+        float x = xy[2 * i], y = xy[2 * i + 1];
+        bool unique = true;
+        for (int j = 0; j < n; ++j) {
+            float dx = x - px[j], dy = y - py[j];
+            if (dx * dx + dy * dy < 0.5f * B2_LINEAR_SLOP) { unique = false; break; }
+        }
+        if (unique) { px[n] = x; py[n] = y; ++n; }
+    }
+    if (n != 4) return false;
+    int i0 = 0;
+    float x0 = px[0];
+    for (int i = 1; i < n; ++i) {
+        float x = px[i];
+        if (x > x0 || (x == x0 && py[i] < py[i0])) { i0 = i; x0 = x; }
+    }
+    int hull[4], m = 0, ih = i0;
+    for (;;) {
+        if (m >= 4) return false;
+        hull[m] = ih;
+        int ie = 0;
+        for (int j = 1; j < n; ++j) {
+            if (ie == ih) { ie = j; continue; }
+            float rx = px[ie] - px[hull[m]], ry = py[ie] - py[hull[m]];
+            float wx = px[j] - px[hull[m]], wy = py[j] - py[hull[m]];
+            float c = rx * wy - ry * wx;
+            if (c < 0.0f) ie = j;
+            if (c == 0.0f && wx * wx + wy * wy > rx * rx + ry * ry) ie = j;
+        }
+        ++m;
+        ih = ie;
+        if (ie == i0) break;
+    }
+    if (m != 4) return false;
+    for (int i = 0; i < 4; ++i) { vx[i] = px[hull[i]]; vy[i] = py[hull[i]]; }
+    for (int i = 0; i < 4; ++i) {
+        int i2 = i + 1 < 4 ? i + 1 : 0;
+        float ex = vx[i2] - vx[i], ey = vy[i2] - vy[i];
+        float tx = 1.0f * ey, ty = -1.0f * ex; // b2Cross(edge, 1.0f)
+        float len = sqrtf(tx * tx + ty * ty);
+        if (!(len < B2_EPSILON)) {
+            float inv = 1.0f / len;
+            tx *= inv;
+            ty *= inv;
+        }
+        nx[i] = tx;
+        ny[i] = ty;
+    }
+    return true;
+}
+
 extern "C" int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, int32_t npts, const float *polys,
                                        int32_t npolys, float friction) {
     if (!w || !xs || !ys || npts < 2) return fail(REM2D_E_INVALID, "terrain needs at least two polyline points");
-    if (npolys != 0 || polys != nullptr)
-        if (npolys != 0)
-            return fail(REM2D_E_INVALID, "hardcore static polygons are not implemented on the HIP path yet");
+    if (npolys < 0 || (npolys > 0 && !polys)) return fail(REM2D_E_INVALID, "bad hardcore polygon list");
     HIP_TRY(hipSetDevice(w->cfg.device));
-    int nEdge = npts - 1;
-    std::vector<float> h((size_t)8 * nEdge);
-    float *v1x = h.data(), *v1y = v1x + nEdge, *v2x = v1y + nEdge, *v2y = v2x + nEdge;
-    float *flx = v2y + nEdge, *fly = flx + nEdge, *fux = fly + nEdge, *fuy = fux + nEdge;
+    const int nEdge = npts - 1, nPoly = npolys, nS = nEdge + nPoly;
+    std::vector<float> h((size_t)20 * nS, 0.0f);
+    float *flx = h.data(), *fly = flx + nS, *fux = fly + nS, *fuy = fux + nS;
+    float *vx = fuy + nS, *vy = vx + 4 * nS, *nx = vy + 4 * nS, *ny = nx + 4 * nS;
+    const float r = B2_POLYGON_RADIUS;
+    for (int i = 0; i < nPoly; ++i) {
+        float pvx[4], pvy[4], pnx[4], pny[4];
+        if (!host_poly_set(polys + (size_t)i * 8, pvx, pvy, pnx, pny))
+            return fail(REM2D_E_INVALID, "hardcore polygons must be convex quads");
+        float lx = 0, ly = 0, ux = 0, uy = 0;
+        for (int k = 0; k < 4; ++k) {
+            vx[k * nS + i] = pvx[k]; vy[k * nS + i] = pvy[k]; nx[k * nS + i] = pnx[k]; ny[k * nS + i] = pny[k];
+            // b2PolygonShape::ComputeAABB with the identity transform
+            float tx = (1.0f * pvx[k] - 0.0f * pvy[k]) + 0.0f, ty = (0.0f * pvx[k] + 1.0f * pvy[k]) + 0.0f;
+            if (k == 0) { lx = ux = tx; ly = uy = ty; }
+            else { lx = lx < tx ? lx : tx; ly = ly < ty ? ly : ty; ux = ux > tx ? ux : tx; uy = uy > ty ? uy : ty; }
+        }
+        flx[i] = (lx - r) - B2_AABB_EXTENSION; fly[i] = (ly - r) - B2_AABB_EXTENSION;
+        fux[i] = (ux + r) + B2_AABB_EXTENSION; fuy[i] = (uy + r) + B2_AABB_EXTENSION;
+    }
     for (int i = 0; i < nEdge; ++i) {
+        const int s = nPoly + i;
         // b2EdgeShape::ComputeAABB with the identity transform, then the broadphase fattening
         float ax = (1.0f * xs[i] - 0.0f * ys[i]) + 0.0f, ay = (0.0f * xs[i] + 1.0f * ys[i]) + 0.0f;
         float bx = (1.0f * xs[i + 1] - 0.0f * ys[i + 1]) + 0.0f, by = (0.0f * xs[i + 1] + 1.0f * ys[i + 1]) + 0.0f;
-        v1x[i] = xs[i]; v1y[i] = ys[i]; v2x[i] = xs[i + 1]; v2y[i] = ys[i + 1];
+        vx[0 * nS + s] = xs[i]; vy[0 * nS + s] = ys[i]; vx[1 * nS + s] = xs[i + 1]; vy[1 * nS + s] = ys[i + 1];
         float lx = ax < bx ? ax : bx, ly = ay < by ? ay : by;
         float ux = ax > bx ? ax : bx, uy = ay > by ? ay : by;
-        const float r = B2_POLYGON_RADIUS;
         lx = lx - r; ly = ly - r; ux = ux + r; uy = uy + r;
-        flx[i] = lx - B2_AABB_EXTENSION; fly[i] = ly - B2_AABB_EXTENSION;
-        fux[i] = ux + B2_AABB_EXTENSION; fuy[i] = uy + B2_AABB_EXTENSION;
+        flx[s] = lx - B2_AABB_EXTENSION; fly[s] = ly - B2_AABB_EXTENSION;
+        fux[s] = ux + B2_AABB_EXTENSION; fuy[s] = uy + B2_AABB_EXTENSION;
     }
-    if (w->terrainBuf) { (void)hipFree(w->terrainBuf); w->terrainBuf = nullptr; }
-    HIP_TRY(hipMalloc((void **)&w->terrainBuf, h.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(w->terrainBuf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-    Terrain &T = w->T;
-    T.nEdge = nEdge;
-    T.nPoly = 0;
-    T.v1x = w->terrainBuf; T.v1y = T.v1x + nEdge; T.v2x = T.v1y + nEdge; T.v2y = T.v2x + nEdge;
-    T.flx = T.v2y + nEdge; T.fly = T.flx + nEdge; T.fux = T.fly + nEdge; T.fuy = T.fux + nEdge;
-    T.x0 = xs[0];
     float pitch = (xs[npts - 1] - xs[0]) / (float)nEdge;
     if (!(pitch > 0.0f)) return fail(REM2D_E_INVALID, "terrain xs must be increasing");
     // the edge scan assumes a (nearly) uniform pitch; verify so that the candidate range is conservative
@@ -2232,6 +2478,16 @@ extern "C" int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const fl
         float expect = xs[0] + pitch * (float)i;
         if (fabsf(xs[i] - expect) > 0.1f * pitch) return fail(REM2D_E_INVALID, "terrain xs must be uniformly spaced");
     }
+    if (w->terrainBuf) { (void)hipFree(w->terrainBuf); w->terrainBuf = nullptr; }
+    HIP_TRY(hipMalloc((void **)&w->terrainBuf, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(w->terrainBuf, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    Terrain &T = w->T;
+    T.nEdge = nEdge;
+    T.nPoly = nPoly;
+    T.nStatic = nS;
+    T.flx = w->terrainBuf; T.fly = T.flx + nS; T.fux = T.fly + nS; T.fuy = T.fux + nS;
+    T.vx = T.fuy + nS; T.vy = T.vx + 4 * nS; T.nx = T.vy + 4 * nS; T.ny = T.nx + 4 * nS;
+    T.x0 = xs[0];
     T.invPitch = 1.0f / pitch;
     T.friction = sqrtf(friction * 0.1f); // b2MixFriction(terrain fixture, module fixture friction 0.1)
     w->haveTerrain = true;

@@ -253,3 +253,29 @@ def test_env_step_reward_and_wall_of_death(oracle, rough_terrain):
         assert r == x and d == 0
     else:
         pytest.fail("wall of death never caught the creature")
+
+
+def test_static_box_terrain_contacts(oracle):
+    """Hardcore obstacles: a module box resting on a static box gets a 2-point polygon-polygon manifold
+    (reference face on the terrain box, normal up); a circle gets a 1-point face manifold.  Modules do
+    not collide with each other (category 0x20 / mask 0x1), so both rest directly on the stump."""
+    xs = (np.arange(60) * (14 / 30.0)).astype(np.float32)
+    ys = np.full(60, 5.0, np.float32)
+    stump = np.array([[[10.0, 5.0], [11.0, 5.0], [11.0, 6.0], [10.0, 6.0]]], np.float32)  # clockwise like the reference
+    t = oracle.Terrain(xs, ys, stump)
+    w = oracle.World(t)
+    w.add_box(0.2, 0.2, 10.5, 6.3, 0)
+    w.add_circle(0.25, 10.3, 8.0, 0)
+    for _ in range(150):
+        w.step()
+    b = w.bodies()
+    assert 6.0 + 0.2 + 0.015 - 1e-3 <= b[0][1] <= 6.0 + 0.2 + 0.02 + 1e-3  # skin gap in [2r - slop, 2r]
+    c, f = w.contacts(0)
+    row = c[c[:, 0] == 0][0]                                              # static proxy 0 = the stump
+    assert row[1] == 2 and row[2] == 1                                    # two points, e_faceA
+    man = w.manifold(0, int(np.argmax(c[:, 0] == 0)))
+    assert man[0] == pytest.approx(0.0, abs=1e-6) and man[1] == pytest.approx(1.0, abs=1e-6)
+    assert float(f[0][:2].sum()) == pytest.approx(0.16 * 10 * 0.02, rel=1e-3)  # carries the box weight
+    assert 6.0 + 0.25 + 0.005 - 1e-3 <= b[1][1] <= 6.0 + 0.25 + 0.01 + 1e-3
+    c1, _ = w.contacts(1)
+    assert c1[c1[:, 0] == 0][0][1] == 1

@@ -134,6 +134,46 @@ def test_continuous_physics_bit_exact(gpu, oracle, rough_terrain, name):
     w.close()
 
 
+@pytest.mark.parametrize("continuous", [False, True])
+def test_hardcore_terrain_bit_exact(gpu, oracle, continuous):
+    """bipedal-walker-hardcore track (pits / stumps / stairs = static boxes): b2CollidePolygons and
+    b2CollidePolygonAndCircle against terrain boxes, box proxies ahead of the edges in pair order.
+    Creatures are dropped along the track so that they actually land on the obstacles."""
+    from gym_rem2d_amd import _lib, make_terrain, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    terrain = make_terrain(4, hardcore=True)
+    assert len(terrain.polys) == 29
+    specs = synthetic.lsystem_specs(range(40), mutate_odd=True)
+    morph = Morphology.from_specs(specs, 32)
+    # spread the creatures over the first obstacles: shift x by a multiple of 1.4 m (positions are float32 inputs)
+    xs = terrain.polys[:, :, 0]
+    first = float(xs.min())
+    shift = (np.arange(morph.n_envs) % 20) * 1.4 + (first - 7.0)
+    a = morph.arrays
+    K = morph.lanes
+    for e in range(morph.n_envs):
+        sl = slice(e * K, (e + 1) * K)
+        live = a["shape"][sl] != 0
+        a["x"][sl][live] = (a["x"][sl][live] + np.float32(shift[e])).astype(np.float32)
+        a["y"][sl][live] = (a["y"][sl][live] + np.float32(2.0)).astype(np.float32)
+    flags_g = _lib.FLAG_CONTINUOUS if continuous else 0
+    flags_o = oracle.FLAG_CONTINUOUS if continuous else 0
+    T = 260
+    ref = oracle.batch_run(oracle_terrain(oracle, terrain), morph.as_dict(), T, n_threads=8, trace=True, flags=flags_o)
+    w, snaps = _run_gpu(gpu, morph, terrain, [1, 9, 50, 200], flags_g)
+    t = 0
+    for c, sn in zip([1, 9, 50, 200], snaps):
+        t += c
+        assert np.array_equal(sn[..., :3], ref["trace"][t - 1]), "pose mismatch at step %d" % t
+    assert np.array_equal(snaps[-1], ref["bodies"])
+    assert int(w.view("err").max()) == 0
+    # the boxes are really hit: some pair slots reference static proxies below the edge range
+    cedge, cinfo = w.view("cedge").cpu().numpy(), w.view("cinfo").cpu().numpy()
+    hit = (cedge >= 0) & (cedge < 29) & ((cinfo & 0xff) > 0)
+    assert hit.sum() > 0
+    w.close()
+
+
 def test_multi_step_launch_equals_single_steps(gpu, rough_terrain):
     morph = _populations()["direct"]
     _, a = _run_gpu(gpu, morph, rough_terrain, [1] * 60)
