@@ -32,6 +32,27 @@ def algorithmic_bytes(n_bodies):
     return 72 * M + 100 * np.maximum(M - 1, 0) + 48 * (2 * M) + 12
 
 
+def valu_flops_per_env_step(n_bodies, vel_iters=180):
+    """Counted binary32 operations of the velocity loop per env-step (the part that dominates): per
+    iteration a revolute joint costs ~105 flop (motor + 2x2 point solve; ~190 with an active limit) and
+    a 2-point contact ~150 flop (two friction rows + block solver).  Estimate with one joint per
+    non-root body and one 2-point contact per two bodies."""
+    M = np.asarray(n_bodies, dtype=np.float64)
+    return vel_iters * (105.0 * np.maximum(M - 1, 0) + 150.0 * 0.5 * M)
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_b_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command)."""
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d["kernels"][kernel_name]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def build_population(workload, n_envs, rank):
     """Host-side synthetic input, built BEFORE the GPU is initialised (uses a fork pool)."""
     from gym_rem2d_amd import synthetic
@@ -173,6 +194,11 @@ def main():
     avg_ms = ms / max(1, launches)
     achieved = bytes_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     err = int(env.errors().max())
+    kname = "rem2d_step_kernel<%d>" % m.lanes
+    traffic_bytes, traffic_src = (pmc_traffic(kname) if (args.workload == "lsystem" and not args.discrete and n_envs == 65536)
+                                  else (None, None))
+    traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
+    valu = float(valu_flops_per_env_step(m.n_bodies).sum()) * steps_per_launch_avg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
 
     if rank == 0:
         out = {
@@ -195,9 +221,9 @@ def main():
                        "parallelism": "population sharded over %d GPU(s), no per-step collective" % world,
                        "solver_errors": err},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "rem2d_step_kernel<%d>" % m.lanes, "avg_launch_ms": avg_ms,
-                         "launches": launches,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "avg_launch_ms": avg_ms, "launches": launches,
+                         "valu_tflops_est": valu, "valu_frac_of_157.3": valu / 157.3,
                          "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d); "
                                  "the path is FP32-VALU/latency bound, not HBM bound"},
         }
