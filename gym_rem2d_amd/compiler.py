@@ -19,7 +19,7 @@ TERRAIN_HEIGHT = 600 / 30.0 / 4      # VIEWPORT_H/SCALE/4 (Modular2DEnv.py:59)
 SPAWN = (5, TERRAIN_HEIGHT + 2, 0)   # root position (Modular2DEnv.py:429-432)
 
 SHAPE_NONE, SHAPE_BOX, SHAPE_CIRCLE = 0, 1, 2
-MAX_LANES = 32
+MAX_LANES = 64
 
 MORPH_I32 = ("shape", "parent", "jround")
 MORPH_F32 = ("hx", "hy", "x", "y", "angle", "ax", "ay", "bx", "by", "torque", "lower", "upper")

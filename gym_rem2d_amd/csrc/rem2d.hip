@@ -1482,9 +1482,22 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
         sw.c0 = mk(cx, cy);
         sw.a0 = ca;
         // InitializeVelocityConstraints without warm starting, then velIters sweeps over the island contacts
+        // (the first KR constraints stay in registers, further ones -- rare -- go through scratch)
         {
             Rot qn = rot_set(ca);
-            for (int t = 0; t < nIsl; ++t) {
+            ContactC tcc[KR];
+#pragma unroll
+            for (int t = 0; t < KR; ++t) {
+                tcc[t].count = 0;
+                if (t < nIsl) {
+                    const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
+                    int tc = __float_as_int(SW(sb, 0));
+                    contact_setup(tcc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
+                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f,
+                                  0.0f, 0.0f);
+                }
+            }
+            for (int t = KR; t < nIsl; ++t) {
                 const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
                 int tc = __float_as_int(SW(sb, 0));
                 ContactC c;
@@ -1492,14 +1505,17 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                               mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
                 cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
             }
-        }
-        for (int it = 0; it < velIters; ++it) {
-            for (int t = 0; t < nIsl; ++t) {
-                const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
-                ContactC c;
-                cc_load(S, cb, c);
-                contact_solve(c, mB, iB, friction, B.vx, B.vy, B.w);
-                SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+            for (int it = 0; it < velIters; ++it) {
+#pragma unroll
+                for (int t = 0; t < KR; ++t)
+                    if (t < nIsl) contact_solve(tcc[t], mB, iB, friction, B.vx, B.vy, B.w);
+                for (int t = KR; t < nIsl; ++t) {
+                    const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
+                    ContactC c;
+                    cc_load(S, cb, c);
+                    contact_solve(c, mB, iB, friction, B.vx, B.vy, B.w);
+                    SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+                }
             }
         }
         // integrate the remaining (1 - minAlpha) * dt; TOI impulses are not stored
@@ -1618,8 +1634,10 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
     float motorSpeed = LF(L_JMOTORSPEED);
     const float mA = __shfl(mB, pl), iA = __shfl(iB, pl);
     const int nRounds = wave_max(jround) + 1;
-    const int childMask = group_or<K>(hasJoint ? (1 << parent) : 0);
-    const bool jointed = hasJoint || ((childMask >> sub) & 1); // SetMotorSpeed wakes both bodies
+    // bit b of childMask: some lane of this creature hangs off body b (K <= 64 -> two 32-bit halves)
+    const int childLo = group_or<K>((hasJoint && parent < 32) ? (1 << parent) : 0);
+    const int childHi = group_or<K>((hasJoint && parent >= 32) ? (1 << (parent - 32)) : 0);
+    const bool jointed = hasJoint || (((sub < 32 ? childLo >> sub : childHi >> (sub - 32))) & 1); // SetMotorSpeed wakes both bodies
     float invDt0 = EF(E_INVDT0);
     int newFix = EI(E_NEWFIX), err = 0, lastPosIters = EI(E_POSITERS);
 
@@ -2298,7 +2316,7 @@ extern "C" const char *rem2d_last_error(void) { return g_err.c_str(); }
 static bool cfg_ok(const rem2d_world_cfg *cfg) {
     if (!cfg || cfg->n_envs <= 0) return false;
     int k = cfg->lanes;
-    return k == 2 || k == 4 || k == 8 || k == 16 || k == 32;
+    return k == 2 || k == 4 || k == 8 || k == 16 || k == 32 || k == 64;
 }
 extern "C" size_t rem2d_state_bytes(const rem2d_world_cfg *cfg) {
     if (!cfg_ok(cfg)) return 0;
@@ -2326,7 +2344,7 @@ static void bind_state(rem2d_world *w) {
 extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, size_t state_bytes, rem2d_world **out) {
     if (!out) return fail(REM2D_E_INVALID, "out is NULL");
     *out = nullptr;
-    if (!cfg_ok(cfg)) return fail(REM2D_E_INVALID, "cfg: n_envs must be > 0 and lanes one of 2,4,8,16,32");
+    if (!cfg_ok(cfg)) return fail(REM2D_E_INVALID, "cfg: n_envs must be > 0 and lanes one of 2,4,8,16,32,64");
     Layout L = make_layout(cfg);
     if (!state_dev || state_bytes < L.total) return fail(REM2D_E_INVALID, "state buffer missing or too small");
     // 32-bit per-lane byte offsets: (slots * Lp + lane) * 4 and (scratch words * Lp + lane) * 4 must fit
@@ -2538,7 +2556,8 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
         case 4: hipLaunchKernelGGL(rem2d_step_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
         case 8: hipLaunchKernelGGL(rem2d_step_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
         case 16: hipLaunchKernelGGL(rem2d_step_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
-        default: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+        case 32: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+        default: hipLaunchKernelGGL(rem2d_step_kernel<64>, grid, block, 0, st, w->S, w->T, A); break;
         }
         if (w->timing) {
             HIP_TRY(hipEventRecord(e1, st));
@@ -2550,7 +2569,8 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
             case 4: hipLaunchKernelGGL(rem2d_toi_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
             case 8: hipLaunchKernelGGL(rem2d_toi_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
             case 16: hipLaunchKernelGGL(rem2d_toi_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
-            default: hipLaunchKernelGGL(rem2d_toi_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+            case 32: hipLaunchKernelGGL(rem2d_toi_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
+            default: hipLaunchKernelGGL(rem2d_toi_kernel<64>, grid, block, 0, st, w->S, w->T, A); break;
             }
         }
     }

@@ -14,7 +14,7 @@
  *
  * Data layout in HBM: structure of arrays, one 4- or 8-byte element per (creature, lane),
  * lane fastest.  One lane = one rigid body (+ the revolute joint to its parent + the
- * controller of the node that created it); `lanes` (2..32, power of two) consecutive lanes
+ * controller of the node that created it); `lanes` (2..64, power of two) consecutive lanes
  * of one 64-wide wavefront form one creature, so a wave steps 64/lanes creatures in lockstep.
  */
 #ifndef REM2D_H
@@ -42,7 +42,7 @@ enum {
 #define REM2D_FLAG_SLEEP_RESET_ALWAYS 2u /* b2Body::SetAwake(true) always zeroes sleepTime */
 #define REM2D_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
 
-#define REM2D_MAX_LANES 32
+#define REM2D_MAX_LANES 64
 #define REM2D_CONTACT_SLOTS 24 /* broadphase pair slots per body */
 #define REM2D_SOLVER_SLOTS 6  /* touching contacts per body that enter the solver */
 
@@ -50,7 +50,7 @@ typedef struct rem2d_world rem2d_world;
 
 typedef struct {
     int32_t n_envs; /* creatures (independent b2Worlds) */
-    int32_t lanes;  /* lanes per creature: 2, 4, 8, 16 or 32 */
+    int32_t lanes;  /* lanes per creature: 2, 4, 8, 16, 32 or 64 */
     uint32_t flags; /* REM2D_FLAG_* */
     int32_t device; /* HIP device ordinal */
 } rem2d_world_cfg;

@@ -192,7 +192,7 @@ class World:
         return out
 
     def island_joint_order(self):
-        out = np.zeros(64, dtype=np.int32)
+        out = np.zeros(128, dtype=np.int32)
         n = lib().rem2d_oracle_get_island_joint_order(self.h, _ptr(out))
         return out[:n].copy()
 

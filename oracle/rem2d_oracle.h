@@ -29,7 +29,7 @@ extern "C" {
 #define O_FLAG_SLEEP_RESET_ALWAYS 2u /* b2Body::SetAwake(true) always zeroes sleepTime (pre-2.3.1 variant) */
 #define O_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
 
-#define O_MAX_BODIES 32
+#define O_MAX_BODIES 64
 #define O_MAX_BODY_CONTACTS 24
 
 typedef struct o_terrain o_terrain;

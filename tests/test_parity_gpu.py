@@ -174,6 +174,30 @@ def test_hardcore_terrain_bit_exact(gpu, oracle, continuous):
     w.close()
 
 
+def test_reference_default_size_creatures_k64(gpu, oracle, rough_terrain):
+    """0.cfg allows max_size = 40 (up to 41 bodies): one creature per wavefront (64 lanes)."""
+    import random
+    from gym_rem2d_amd import _lib, build_creature, ea
+    from gym_rem2d_amd.compiler import Morphology
+    random.seed(1)
+    cfg = ea.make_config(population_size=64, encoding="lsystem")
+    specs = []
+    for _ in range(64):
+        ind = ea.Individual.random(config=cfg)
+        spec = build_creature(ind.genome.create(7).getNodes(), ind.genome.moduleList)[0]
+        if spec.n_bodies > 32:
+            specs.append(spec)
+    assert len(specs) >= 5 and max(s.n_bodies for s in specs) >= 40
+    morph = Morphology.from_specs(specs)
+    assert morph.lanes == 64
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), 150, n_threads=8,
+                           flags=oracle.FLAG_CONTINUOUS)
+    w, snaps = _run_gpu(gpu, morph, rough_terrain, [1, 49, 100], _lib.FLAG_CONTINUOUS)
+    assert np.array_equal(snaps[-1], ref["bodies"])
+    assert int(w.view("err").max()) == 0
+    w.close()
+
+
 def test_multi_step_launch_equals_single_steps(gpu, rough_terrain):
     morph = _populations()["direct"]
     _, a = _run_gpu(gpu, morph, rough_terrain, [1] * 60)
