@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-from .encodings import DirectEncoding, LSystem
+from .encodings import DirectEncoding, LSystem, NNEncoding
 from .modules import get_module_list
 
 DEFAULTS = dict(population_size=100, n_evaluations=10000, mutation_prob=0.01, morphmutation_prob=0.01,
@@ -45,9 +45,12 @@ class Individual:
             self.genome = DirectEncoding(moduleList, config)
         elif encoding == "lsystem":
             self.genome = LSystem(moduleList, config)
+        elif encoding == "cppn":
+            # neat-python is absent from the image: the genome is a synthetic feed-forward CPPN
+            self.genome = NNEncoding(moduleList, config=config)
         else:
-            raise Exception("encoding %r is not available in this build (supported: 'direct', 'lsystem'); "
-                            "'cppn' / 'ce' need neat-python, which the reference pins but the image lacks" % encoding)
+            raise Exception("encoding %r is not available in this build (supported: 'direct', 'lsystem', 'cppn'); "
+                            "'ce' (cellular encoding) is genotype-only code outside the accelerated path" % encoding)
         self.genome.create(self.tree_depth)
         return self
 

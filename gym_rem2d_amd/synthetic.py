@@ -13,7 +13,7 @@ import numpy as np
 
 from .compiler import Morphology, build_creature, lanes_for
 from .controller import Controller
-from .encodings import DirectEncoding, LSystem
+from .encodings import DirectEncoding, LSystem, NNEncoding
 from .modules import BoxConnection, Standard2D, get_module_list
 from .tree import Node, Tree
 
@@ -85,3 +85,16 @@ def lsystem_population(n_envs, lanes=16, n_unique=None, seed0=0):
         return uniq
     idx = np.arange(n_envs) % n_unique
     return uniq.take(idx)
+
+
+def cppn_specs(seeds):
+    """Config 4 input: one network-encoded creature per seed (synthetic feed-forward CPPN genome)."""
+    specs = []
+    for seed in seeds:
+        random.seed(int(seed))
+        ml = get_module_list()
+        g = NNEncoding(ml)
+        tree = g.create(7)
+        spec, _, _ = build_creature(tree.getNodes(), g.moduleList)
+        specs.append(spec)
+    return specs

@@ -47,8 +47,14 @@ def test_individual_random_matches_module_defaults():
     clone = copy.deepcopy(ind)
     clone.mutate(0.5, 0.5, 0.5)
     assert ind.genome is not clone.genome
-    with pytest.raises(Exception, match="neat-python"):
-        ea.Individual.random(encoding="cppn")
+    with pytest.raises(Exception, match="cellular"):
+        ea.Individual.random(encoding="ce")
+    net = ea.Individual.random(encoding="cppn")
+    nodes = net.genome.create(7).getNodes()
+    assert nodes[0].parent == -1 and nodes[0].type == -1 and len(nodes) <= 22  # axiom moduleRef -1 as in the reference
+    for n in nodes[1:]:
+        assert n.parent_connection_coordinates is not None and n.controller is not None
+        assert 0.5 <= getattr(n.module_, "width", 0.5) <= 1.0
 
 
 @pytest.mark.gpu
