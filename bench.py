@@ -13,6 +13,10 @@ Workloads (BASELINE.json configs), all synthetic:
            lane count (2/4/8/16) so that waves are homogeneous
   chain8   65 536 identical 8-module chains (north_star's "8-module creatures")
   chain4   4 096 identical 4-module chains (config 2)
+  cppn_hardcore  65 536 network-encoded creatures (synthetic CPPN genome) on the hardcore track (config 4)
+  generation     config 5's unit of work: every rank evaluates 131 072 L-system individuals for whole
+                 episodes (until every fitness is final, <= 2500 steps) and the ranks all-gather the fitness;
+                 `--steps` is ignored, the JSON reports env-steps/s over the executed steps
 """
 import argparse
 import json
@@ -67,8 +71,9 @@ def build_population(workload, n_envs, rank):
     seeds = np.arange(rank * n_envs, (rank + 1) * n_envs)
     n_proc = max(1, min(8, os.cpu_count() or 1))
     chunks = np.array_split(seeds, n_proc * 8)
+    maker = synthetic.cppn_specs if workload == "cppn_hardcore" else synthetic.lsystem_specs
     with mp.get_context("fork").Pool(n_proc) as pool:
-        parts = pool.map(synthetic.lsystem_specs, [c.tolist() for c in chunks])
+        parts = pool.map(maker, [c.tolist() for c in chunks])
     specs = [s for p in parts for s in p]
     groups = {}
     for s in specs:
@@ -77,6 +82,9 @@ def build_population(workload, n_envs, rank):
     for k in groups:
         groups[k].sort(key=lambda s: (max(s.rounds, default=-1), s.n_bodies))
     morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
+    if workload == "cppn_hardcore":
+        return morphs, ("%d network-encoded creatures (synthetic feed-forward CPPN genome, seeds %d..%d), hardcore "
+                        "terrain (pits/stumps/stairs), bucketed by lane count %s" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
     return morphs, ("%d random L-System creatures (seeds %d..%d, maxModules=15, <=16 bodies), flat terrain, "
                     "bucketed by lane count %s and sorted by joint rounds" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
 
@@ -86,7 +94,8 @@ def cpu_baseline(morphs, terrain, budget_s=12.0, flags=0):
     from oracle import oracle as O
     O.build()
     xs, ys, _ = terrain.f32()
-    ot = O.Terrain(xs, ys, None, terrain.friction)
+    xs, ys, polys = terrain.f32()
+    ot = O.Terrain(xs, ys, polys if len(polys) else None, terrain.friction)
     cores = os.cpu_count() or 1
     # sample: a proportional slice of every bucket (>= 4 creatures per host thread), 50 steps from reset;
     # repeated until the time budget is used
@@ -113,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lsystem", choices=["lsystem", "chain8", "chain4"])
+    ap.add_argument("--workload", default="lsystem", choices=["lsystem", "chain8", "chain4", "cppn_hardcore", "generation"])
     ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (default: config size)")
     ap.add_argument("--steps-per-launch", type=int, default=10)
     ap.add_argument("--settle", type=int, default=60,
@@ -126,9 +135,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_envs = args.envs or (4096 if args.workload == "chain4" else 65536)
+    n_envs = args.envs or {"chain4": 4096, "generation": 131072}.get(args.workload, 65536)
+    generation = args.workload == "generation"
 
-    morphs, workload_desc = build_population(args.workload, n_envs, rank)
+    morphs, workload_desc = build_population("lsystem" if generation else args.workload, n_envs, rank)
+    if generation:
+        workload_desc = "one EA generation: whole episodes (evaluate() rule, <= 2500 steps) of " + workload_desc
 
     import torch
     import torch.distributed as dist
@@ -142,7 +154,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from gym_rem2d_amd import _lib
-    env = BatchedModular2D(flat=True, seed=4, device=dev, flags=0 if args.discrete else _lib.FLAG_CONTINUOUS)
+    hard = args.workload == "cppn_hardcore"
+    env = BatchedModular2D(flat=not hard, hardcore=hard, seed=4, device=dev,
+                           flags=0 if args.discrete else _lib.FLAG_CONTINUOUS)
     batches, lo = [], 0
     for m in morphs:
         batches.append((m, list(range(lo, lo + m.n_envs))))
@@ -164,6 +178,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if generation:
+        args.settle = args.warmup = 0
     run(args.settle)
     run(args.warmup)
     for w, _ in env.worlds:
@@ -171,7 +187,17 @@ def main():
         w.kernel_time_ms()
     sync()
     t0 = time.perf_counter()
-    run(args.steps)
+    if generation:
+        from gym_rem2d_amd.evaluate import EPISODE_CAP
+        done_steps = 0
+        while done_steps < EPISODE_CAP:
+            env.step(100)
+            done_steps += 100
+            if bool((env.frozen != 0).all()):
+                break
+        args.steps = done_steps
+    else:
+        run(args.steps)
     fit = env.fitness.to(torch.float32)
     if world > 1:
         fit = all_gather_fitness(fit, n_envs * world)  # the generation's only collective
@@ -229,7 +255,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             from gym_rem2d_amd import make_terrain as _mt
-            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=True), flags=0 if args.discrete else 1)
+            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=not hard, hardcore=hard), flags=0 if args.discrete else 1)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))
