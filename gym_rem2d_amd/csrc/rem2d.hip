@@ -1351,6 +1351,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
         CI(C_INFO, o) = CI(C_INFO, o) & (0xffff | CI_ENABLED);
     }
     const Proxy pB = proxy_body(shape, hx, hy);
+    const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f; // circumradius of the core shape
     for (;;) {
         int minSlot = -1;
         float minAlpha = 1.0f;
@@ -1367,12 +1368,34 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 int e = CI(C_EDGE, o);
                 Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
                 if (e < T.nPoly) { pA.v[2] = static_vert(T, e, 2); pA.v[3] = static_vert(T, e, 3); pA.count = 4; }
-                int state;
-                float t;
-                time_of_impact(state, t, pA, pB, sw);
-                float beta = t;
-                if (state == TOI_TOUCHING) alpha = fmin32(alpha0 + (1.0f - alpha0) * beta, 1.0f);
-                else alpha = 1.0f;
+                // Conservative exact skip.  b2TimeOfImpact can only answer e_touching if some core-shape
+                // distance / separation it evaluates for t in [0,1] falls below target + tolerance, and every
+                // such value is >= the true distance of the core shapes at that t.  The body's core stays inside
+                // the disk of radius coreR around its centre, which moves on the segment c0 -> c: if that
+                // capsule's bounding box keeps more than target + tolerance (+ 5 mm for rounding) away from
+                // the static shape's bounding box, the answer is alpha = 1 without running GJK.
+                bool farApart;
+                {
+                    V2 slo = pA.v[0], shi = pA.v[0];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (k < pA.count) { slo = vmin2(slo, pA.v[k]); shi = vmax2(shi, pA.v[k]); }
+                    V2 blo = vsub(vmin2(sw.c0, sw.c), mk(coreR, coreR)), bhi = vadd(vmax2(sw.c0, sw.c), mk(coreR, coreR));
+                    float gap = fmax32(fmax32(blo.x - shi.x, slo.x - bhi.x), fmax32(blo.y - shi.y, slo.y - bhi.y));
+                    float totalRadius = pA.radius + pB.radius;
+                    float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
+                    farApart = gap > target + 0.25f * B2_LINEAR_SLOP + 0.005f;
+                }
+                if (farApart) {
+                    alpha = 1.0f;
+                } else {
+                    int state;
+                    float t;
+                    time_of_impact(state, t, pA, pB, sw);
+                    float beta = t;
+                    if (state == TOI_TOUCHING) alpha = fmin32(alpha0 + (1.0f - alpha0) * beta, 1.0f);
+                    else alpha = 1.0f;
+                }
                 SW((unsigned)(SCR_TOI_BASE + s) * Lp + gl, 0) = alpha;
                 CI(C_INFO, o) = info | CI_TOIFLAG;
             }
@@ -1506,16 +1529,34 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
             }
             for (int it = 0; it < velIters; ++it) {
+                // Exact early exit: one sweep is a deterministic function of (velocity, impulses); a sweep
+                // that changes no bit is a fixed point, so every later sweep is the identity.  (Single-body
+                // contact-only systems reach it after ~10 sweeps; the full 180 are never needed.)
+                unsigned h0 = __float_as_uint(B.vx), h1 = __float_as_uint(B.vy), h2 = __float_as_uint(B.w);
+                bool changed = false;
 #pragma unroll
-                for (int t = 0; t < KR; ++t)
-                    if (t < nIsl) contact_solve(tcc[t], mB, iB, friction, B.vx, B.vy, B.w);
+                for (int t = 0; t < KR; ++t) {
+                    if (t < nIsl) {
+                        const unsigned a0 = __float_as_uint(tcc[t].n0), a1 = __float_as_uint(tcc[t].n1);
+                        const unsigned a2 = __float_as_uint(tcc[t].t0), a3 = __float_as_uint(tcc[t].t1);
+                        contact_solve(tcc[t], mB, iB, friction, B.vx, B.vy, B.w);
+                        changed |= a0 != __float_as_uint(tcc[t].n0) || a1 != __float_as_uint(tcc[t].n1) ||
+                                   a2 != __float_as_uint(tcc[t].t0) || a3 != __float_as_uint(tcc[t].t1);
+                    }
+                }
                 for (int t = KR; t < nIsl; ++t) {
                     const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
                     ContactC c;
                     cc_load(S, cb, c);
+                    const unsigned a0 = __float_as_uint(c.n0), a1 = __float_as_uint(c.n1);
+                    const unsigned a2 = __float_as_uint(c.t0), a3 = __float_as_uint(c.t1);
                     contact_solve(c, mB, iB, friction, B.vx, B.vy, B.w);
+                    changed |= a0 != __float_as_uint(c.n0) || a1 != __float_as_uint(c.n1) || a2 != __float_as_uint(c.t0) ||
+                               a3 != __float_as_uint(c.t1);
                     SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
                 }
+                changed |= h0 != __float_as_uint(B.vx) || h1 != __float_as_uint(B.vy) || h2 != __float_as_uint(B.w);
+                if (!changed) break;
             }
         }
         // integrate the remaining (1 - minAlpha) * dt; TOI impulses are not stored
@@ -2153,7 +2194,7 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T,
 // with the velocity loop.
 // =====================================================================================
 template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_toi_kernel(State S, Terrain T, StepArgs A) {
+__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_kernel(State S, Terrain T, StepArgs A) {
     const int lane = threadIdx.x;
     const unsigned gl = blockIdx.x * WAVE + lane;
     const unsigned env = gl / K;
