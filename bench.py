@@ -78,9 +78,9 @@ def build_population(workload, n_envs, rank):
     groups = {}
     for s in specs:
         groups.setdefault(lanes_for(s.n_bodies), []).append(s)
-    # creatures of one wave run in lockstep: sort every bucket by (joint rounds, bodies)
+    # creatures of one wave run in lockstep: sort every bucket by (pipeline period, joint rounds, bodies)
     for k in groups:
-        groups[k].sort(key=lambda s: (max(s.rounds, default=-1), s.n_bodies))
+        groups[k].sort(key=lambda s: (s.period, max(s.rounds, default=-1), s.n_bodies))
     morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
     if workload == "cppn_hardcore":
         return morphs, ("%d network-encoded creatures (synthetic feed-forward CPPN genome, seeds %d..%d), hardcore "

@@ -96,7 +96,7 @@ class BatchedModular2D:
         batches = []
         for lanes in sorted(groups):
             # creatures of one wave run in lockstep: keep waves homogeneous in joint rounds / size
-            idx = sorted(groups[lanes], key=lambda e: (max(specs[e].rounds, default=-1), specs[e].n_bodies))
+            idx = sorted(groups[lanes], key=lambda e: (specs[e].period, max(specs[e].rounds, default=-1), specs[e].n_bodies))
             batches.append((Morphology.from_specs([specs[e] for e in idx], lanes), idx))
         self._upload(batches, len(specs))
 

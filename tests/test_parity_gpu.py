@@ -252,8 +252,10 @@ def test_full_size_replicas_agree(gpu, oracle, flat_terrain):
     w.close()
     uniq = Morphology.from_specs([s for s in synthetic.lsystem_specs(range(400)) if s.n_bodies <= 16][:256], 16)
     tiled = uniq.take(np.arange(N) % 256)
-    w, _ = _run_gpu(gpu, tiled, flat_terrain, [60])
-    ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), uniq.as_dict(), 60, n_threads=8)
+    from gym_rem2d_amd import _lib
+    w, _ = _run_gpu(gpu, tiled, flat_terrain, [60], _lib.FLAG_CONTINUOUS)
+    ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), uniq.as_dict(), 60, n_threads=8,
+                           flags=oracle.FLAG_CONTINUOUS)
     px = w.view("px").view(N // 256, 256, 16)
     assert bool((px == px[0:1]).all())
     assert np.array_equal(w.bodies()[:256], ref["bodies"])
