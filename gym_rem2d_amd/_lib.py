@@ -53,8 +53,9 @@ class Rem2dError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so (hipcc cross-compiles
     without a GPU).  -ffp-contract=off keeps every binary32 operation separately rounded."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(_ROOT, "include", "rem2d.h"))):
+    csrc = os.path.dirname(SRC_PATH)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "rem2d.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(_ROOT, "include"), SRC_PATH, "-o", LIB_PATH]

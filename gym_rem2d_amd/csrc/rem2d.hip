@@ -64,2317 +64,12 @@ enum { MF_CIRCLES = 0, MF_FACE_A = 1, MF_FACE_B = 2 };
 enum { LIM_INACTIVE = 0, LIM_AT_LOWER = 1, LIM_AT_UPPER = 2, LIM_EQUAL = 3 };
 enum { CF_VERTEX = 0, CF_FACE = 1 };
 
-// =====================================================================================
-// state arena: field-major with ONE stride per group, so that a kernel address is
-//   (scalar group base + field * stride)  +  (32-bit per-lane byte offset shared by all fields)
-// i.e. global_load/store with an SGPR base and one VGPR offset -- no per-array address VGPRs.
-// =====================================================================================
-struct FieldDesc { int group; int index; int dtype; }; // group: 0 lane4, 1 lane8, 2 slot4, 3 env4, 4 env8
-enum { G_LANE4 = 0, G_LANE8 = 1, G_SLOT4 = 2, G_ENV4 = 3, G_ENV8 = 4 };
-// per-lane 4-byte fields, same order as REM2D_F_PX .. REM2D_F_CCOUNT
-enum {
-    L_PX = 0, L_PY, L_ANG, L_VX, L_VY, L_W, L_SLEEPT, L_HX, L_HY, L_INVM, L_INVI, L_FATLX, L_FATLY, L_FATUX, L_FATUY,
-    L_JAX, L_JAY, L_JBX, L_JBY, L_JTORQUE, L_JLOWER, L_JUPPER, L_JIMPX, L_JIMPY, L_JIMPZ, L_JMOTORIMP, L_JMOTORSPEED,
-    L_SHAPE, L_PARENT, L_JROUND, L_AWAKE, L_JLIMIT, L_CCOUNT, L4_COUNT
-};
-enum { D_CAMP = 0, D_CPHASE, D_CFREQ, D_COFFSET, D_CISTATE, L8_COUNT };
-enum { C_EDGE = 0, C_INFO, C_KEY0, C_KEY1, C_N0, C_N1, C_T0, C_T1, S4_COUNT };
-enum { E_REWARD = 0, E_DONE, E_EVERDONE, E_FROZEN, E_STEPS, E_INVDT0, E_NEWFIX, E_ERR, E_POSITERS, E_TOIEVENTS, E4_COUNT };
-enum { E_WOD = 0, E_FITNESS, E8_COUNT };
-
-static FieldDesc field_desc(int f) {
-    FieldDesc d;
-    if (f <= REM2D_F_CCOUNT) { d.group = G_LANE4; d.index = f; d.dtype = f >= REM2D_F_SHAPE ? 1 : 0; }
-    else if (f <= REM2D_F_CISTATE) { d.group = G_LANE8; d.index = f - REM2D_F_CAMP; d.dtype = 2; }
-    else if (f <= REM2D_F_CT1) { d.group = G_SLOT4; d.index = f - REM2D_F_CEDGE; d.dtype = f <= REM2D_F_CKEY1 ? 1 : 0; }
-    else if (f == REM2D_F_WOD || f == REM2D_F_FITNESS) { d.group = G_ENV8; d.index = f - REM2D_F_WOD; d.dtype = 2; }
-    else { d.group = G_ENV4; d.index = f - REM2D_F_REWARD; d.dtype = (f == REM2D_F_REWARD || f == REM2D_F_INVDT0) ? 0 : 1; }
-    return d;
-}
-
-struct Layout {
-    int Np, Lp, K;
-    size_t groupOff[5];
-    size_t total;
-};
-static Layout make_layout(const rem2d_world_cfg *cfg) {
-    Layout L;
-    int perWave = WAVE / cfg->lanes;
-    L.K = cfg->lanes;
-    L.Np = (cfg->n_envs + perWave - 1) / perWave * perWave;
-    L.Lp = L.Np * cfg->lanes;
-    size_t o = 0;
-    const size_t sizes[5] = {(size_t)L4_COUNT * L.Lp * 4, (size_t)L8_COUNT * L.Lp * 8, (size_t)S4_COUNT * KC * L.Lp * 4,
-                             (size_t)E4_COUNT * L.Np * 4, (size_t)E8_COUNT * L.Np * 8};
-    const int order[5] = {G_LANE8, G_ENV8, G_LANE4, G_SLOT4, G_ENV4}; // 8-byte groups first
-    for (int k = 0; k < 5; ++k) {
-        L.groupOff[order[k]] = o;
-        o += sizes[order[k]];
-        o = (o + 255) & ~(size_t)255;
-    }
-    L.total = o;
-    return L;
-}
-static void field_place(const Layout &L, int f, size_t *off, size_t *count, int *dtype) {
-    FieldDesc d = field_desc(f);
-    size_t n = 0, esz = d.dtype == 2 ? 8 : 4;
-    switch (d.group) {
-    case G_LANE4: case G_LANE8: n = (size_t)L.Lp; break;
-    case G_SLOT4: n = (size_t)L.Lp * KC; break;
-    default: n = (size_t)L.Np; break;
-    }
-    if (off) *off = L.groupOff[d.group] + (size_t)d.index * n * esz;
-    if (count) *count = n;
-    if (dtype) *dtype = d.dtype;
-}
-
-struct Terrain { // static bodies at the origin, in creation (= broadphase proxy) order: hardcore boxes, then edges
-    int nEdge, nPoly;
-    const float *flx, *fly, *fux, *fuy; // fat AABB of every static proxy            [nPoly + nEdge]
-    const float *vx, *vy;               // vertices [4][nPoly + nEdge] (edges use 0 and 1)
-    const float *nx, *ny;               // polygon normals [4][nPoly + nEdge]
-    int nStatic;
-    float x0, invPitch;
-    float friction; // b2MixFriction(terrain, module)
-};
-struct State {
-    char *lane4, *lane8, *slot4, *env4, *env8; // group bases inside the caller's arena
-    float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
-    unsigned Lp, Np, nEnvs, flags;
-};
-// accessors (S, gl and env must be in scope where they are used)
-#define LF(f) (*(float *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))
-#define LI(f) (*(int *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))
-#define LD(f) (*(double *)(S.lane8 + (size_t)(f) * ((size_t)S.Lp * 8) + (gl) * 8u))
-#define CF(f, o32) (*(float *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
-#define CI(f, o32) (*(int *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
-#define CU(f, o32) (*(unsigned *)(S.slot4 + (size_t)(f) * ((size_t)S.Lp * (4 * KC)) + (o32) * 4u))
-#define EF(f) (*(float *)(S.env4 + (size_t)(f) * ((size_t)S.Np * 4) + (env) * 4u))
-#define EI(f) (*(int *)(S.env4 + (size_t)(f) * ((size_t)S.Np * 4) + (env) * 4u))
-#define ED(f) (*(double *)(S.env8 + (size_t)(f) * ((size_t)S.Np * 8) + (env) * 8u))
-// scratch word k of the record that starts at 32-bit word offset base32 (= word0 * Lp + gl)
-#define SW(base32, k) (*(float *)((char *)S.scr + ((base32) + (unsigned)(k) * S.Lp) * 4u))
-
-// =====================================================================================
-// device math (b2Math.h operand order)
-// =====================================================================================
-struct V2 { float x, y; };
-#define DEV __device__ __forceinline__
-DEV V2 mk(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
-DEV V2 vadd(V2 a, V2 b) { return mk(a.x + b.x, a.y + b.y); }
-DEV V2 vsub(V2 a, V2 b) { return mk(a.x - b.x, a.y - b.y); }
-DEV V2 vneg(V2 a) { return mk(-a.x, -a.y); }
-DEV V2 vscale(float s, V2 a) { return mk(s * a.x, s * a.y); }
-DEV float vdot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
-DEV float vcross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
-DEV V2 vcross_vs(V2 a, float s) { return mk(s * a.y, -s * a.x); }
-DEV V2 vcross_sv(float s, V2 a) { return mk(-s * a.y, s * a.x); }
-DEV float vlen(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
-DEV float vdist2(V2 a, V2 b) { V2 c = vsub(a, b); return vdot(c, c); }
-DEV float fmin32(float a, float b) { return a < b ? a : b; }
-DEV float fmax32(float a, float b) { return a > b ? a : b; }
-DEV float fabs32(float a) { return a > 0.0f ? a : -a; }
-DEV float fclamp(float a, float lo, float hi) { return fmax32(lo, fmin32(a, hi)); }
-DEV V2 vmin2(V2 a, V2 b) { return mk(fmin32(a.x, b.x), fmin32(a.y, b.y)); }
-DEV V2 vmax2(V2 a, V2 b) { return mk(fmax32(a.x, b.x), fmax32(a.y, b.y)); }
-DEV float vnormalize(V2 &a) {
-    float length = vlen(a);
-    if (length < B2_EPSILON) return 0.0f;
-    float inv = 1.0f / length;
-    a.x *= inv;
-    a.y *= inv;
-    return length;
-}
-struct Rot { float s, c; };
-DEV V2 rmul(Rot q, V2 v) { return mk(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
-DEV V2 rmulT(Rot q, V2 v) { return mk(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
-DEV V2 xmul(Rot q, V2 p, V2 v) {
-    float x = (q.c * v.x - q.s * v.y) + p.x;
-    float y = (q.s * v.x + q.c * v.y) + p.y;
-    return mk(x, y);
-}
-DEV V2 xmulT(Rot q, V2 p, V2 v) {
-    float px = v.x - p.x, py = v.y - p.y;
-    return mk(q.c * px + q.s * py, -q.s * px + q.c * py);
-}
-
-// ---- trig (DESIGN.md "rem2d trig"): binary64 form for the controller's math.sin ----
-DEV void dev_sincos_d(double x, double &s, double &c) {
-    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
-                 PIO2_1T = 6.07710050650619224932e-11;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double fn = rint(x * INV_PIO2);
-    int n = (int)fn;
-    double r = (x - fn * PIO2_1) - fn * PIO2_1T;
-    double z = r * r;
-    double ps = r + r * (z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))))));
-    double pc = (1.0 - 0.5 * z) + z * z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    int q = n & 3;
-    double ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
-    s = (q == 2 || q == 3) ? -ss : ss;
-    c = (q == 1 || q == 2) ? -cc : cc;
-}
-// b2Rot::Set -- "rem2d trig" binary32 form: 3-term Cody-Waite reduction by pi/2 and the
-// Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4], every operation a separately rounded binary32 op.
-DEV Rot rot_set(float x) {
-    const float TWO_OVER_PI = 0.63661977236758134308f;
-    const float DP1 = 1.5703125f, DP2 = 4.837512969970703125e-4f, DP3 = 7.54978995489188216e-8f;
-    const float S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
-    const float C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
-    float fn = rintf(x * TWO_OVER_PI);
-    int n = (int)fn;
-    float r = ((x - fn * DP1) - fn * DP2) - fn * DP3;
-    float z = r * r;
-    float ps = r + r * (z * (S1 + z * (S2 + z * S3)));
-    float pc = (1.0f - 0.5f * z) + z * z * (C1 + z * (C2 + z * C3));
-    int q = n & 3;
-    float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
-    Rot o;
-    o.s = (q == 2 || q == 3) ? -ss : ss;
-    o.c = (q == 1 || q == 2) ? -cc : cc;
-    return o;
-}
-DEV double dev_sin(double x) {
-    double s, c;
-    dev_sincos_d(x, s, c);
-    return s;
-}
-
-// ---- K-lane group reductions (K consecutive lanes = one creature) ----
-template <int K> DEV float group_min(float v) {
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) {
-        float t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-template <int K> DEV int group_and(int v) {
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) v &= __shfl_xor(v, o);
-    return v;
-}
-template <int K> DEV int group_or(int v) {
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) v |= __shfl_xor(v, o);
-    return v;
-}
-// Mailbox hand-off between lanes of ONE wave (workgroup == wavefront): LDS operations of a wave
-// execute in issue order, so all that is needed is that the compiler neither reorders the LDS
-// accesses across this point nor forwards stale values: release + acquire at workgroup scope
-// (lowers to s_waitcnt lgkmcnt(0)); no s_barrier is required.
-DEV void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-DEV int wave_max(int v) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        int t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-
-// =====================================================================================
-// narrowphase (terrain body A is static at the origin: xfA = identity)
-// =====================================================================================
-struct Manifold {
-    int type, count;
-    V2 ln, lp, p0, p1;
-    unsigned k0, k1;
-};
-DEV unsigned mkkey(int indexA, int indexB, int typeA, int typeB) {
-    return (unsigned)indexA | ((unsigned)indexB << 8) | ((unsigned)typeA << 16) | ((unsigned)typeB << 24);
-}
-
-// b2CollideEdgeAndCircle (circle m_p = 0)
-DEV void collide_edge_circle(Manifold &m, V2 A, V2 B, float rB, V2 center) {
-    m.count = 0;
-    m.type = MF_CIRCLES;
-    m.ln = mk(0.0f, 0.0f);
-    m.lp = mk(0.0f, 0.0f);
-    m.p0 = mk(0.0f, 0.0f);
-    m.p1 = mk(0.0f, 0.0f);
-    m.k0 = m.k1 = 0u;
-    V2 Q = center;
-    V2 e = vsub(B, A);
-    float u = vdot(e, vsub(B, Q));
-    float v = vdot(e, vsub(Q, A));
-    float radius = B2_POLYGON_RADIUS + rB;
-    if (v <= 0.0f) {
-        V2 d = vsub(Q, A);
-        float dd = vdot(d, d);
-        if (dd > radius * radius) return;
-        m.count = 1;
-        m.type = MF_CIRCLES;
-        m.lp = A;
-        m.k0 = mkkey(0, 0, CF_VERTEX, CF_VERTEX);
-        return;
-    }
-    if (u <= 0.0f) {
-        V2 d = vsub(Q, B);
-        float dd = vdot(d, d);
-        if (dd > radius * radius) return;
-        m.count = 1;
-        m.type = MF_CIRCLES;
-        m.lp = B;
-        m.k0 = mkkey(1, 0, CF_VERTEX, CF_VERTEX);
-        return;
-    }
-    float den = vdot(e, e);
-    V2 P = vscale(1.0f / den, vadd(vscale(u, A), vscale(v, B)));
-    V2 d = vsub(Q, P);
-    float dd = vdot(d, d);
-    if (dd > radius * radius) return;
-    V2 n = mk(-e.y, e.x);
-    if (vdot(n, vsub(Q, A)) < 0.0f) n = mk(-n.x, -n.y);
-    vnormalize(n);
-    m.count = 1;
-    m.type = MF_FACE_A;
-    m.ln = n;
-    m.lp = A;
-    m.k0 = mkkey(0, 0, CF_FACE, CF_VERTEX);
-}
-
-struct ClipV { V2 v; int iA, iB, tA, tB; };
-DEV int clip_segment(ClipV (&out)[2], const ClipV (&in)[2], V2 normal, float offset, int vertexIndexA) {
-    int numOut = 0;
-    float distance0 = vdot(normal, in[0].v) - offset;
-    float distance1 = vdot(normal, in[1].v) - offset;
-    ClipV o0 = in[0], o1 = in[1];
-    bool k0 = distance0 <= 0.0f, k1 = distance1 <= 0.0f;
-    // compact without dynamic indexing
-    if (k0 && k1) { out[0] = o0; out[1] = o1; numOut = 2; }
-    else if (k0) { out[0] = o0; out[1] = o0; numOut = 1; }
-    else if (k1) { out[0] = o1; out[1] = o1; numOut = 1; }
-    else { out[0] = o0; out[1] = o0; numOut = 0; }
-    if (distance0 * distance1 < 0.0f) {
-        float interp = distance0 / (distance0 - distance1);
-        ClipV x;
-        x.v = vadd(in[0].v, vscale(interp, vsub(in[1].v, in[0].v)));
-        x.iA = vertexIndexA & 0xff;
-        x.iB = in[0].iB;
-        x.tA = CF_VERTEX;
-        x.tB = CF_FACE;
-        if (numOut == 0) out[0] = x; else out[1] = x; // numOut is 0 or 1 here
-        ++numOut;
-    }
-    return numOut;
-}
-DEV V2 sel4(const V2 (&a)[4], int i) {
-    V2 r = a[0];
-    r = i == 1 ? a[1] : r;
-    r = i == 2 ? a[2] : r;
-    r = i == 3 ? a[3] : r;
-    return r;
-}
-// b2EPCollider::Collide for an isolated edge and a SetAsBox polygon (centroid 0, radius 0.01)
-DEV void collide_edge_box(Manifold &m, V2 v1, V2 v2, float hx, float hy, V2 p, Rot q) {
-    m.count = 0;
-    m.type = MF_FACE_A;
-    m.ln = mk(0.0f, 0.0f);
-    m.lp = mk(0.0f, 0.0f);
-    m.p0 = mk(0.0f, 0.0f);
-    m.p1 = mk(0.0f, 0.0f);
-    m.k0 = m.k1 = 0u;
-    const V2 vloc[4] = {mk(-hx, -hy), mk(hx, -hy), mk(hx, hy), mk(-hx, hy)};
-    const V2 nloc[4] = {mk(0.0f, -1.0f), mk(1.0f, 0.0f), mk(0.0f, 1.0f), mk(-1.0f, 0.0f)};
-    V2 centroidB = xmul(q, p, mk(0.0f, 0.0f));
-    V2 edge1 = vsub(v2, v1);
-    vnormalize(edge1);
-    V2 normal1 = mk(edge1.y, -edge1.x);
-    float offset1 = vdot(normal1, vsub(centroidB, v1));
-    bool front = offset1 >= 0.0f;
-    V2 normal = front ? normal1 : vneg(normal1);
-    V2 limit = front ? vneg(normal1) : normal1; // lowerLimit == upperLimit for an isolated edge
-    V2 pv[4], pn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        pv[i] = xmul(q, p, vloc[i]);
-        pn[i] = rmul(q, nloc[i]);
-    }
-    const float radius = 2.0f * B2_POLYGON_RADIUS;
-    float edgeSep = FLT_MAX;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float s = vdot(normal, vsub(pv[i], v1));
-        if (s < edgeSep) edgeSep = s;
-    }
-    if (edgeSep > radius) return;
-    // ComputePolygonSeparation
-    int polyIndex = -1;
-    float polySep = -FLT_MAX;
-    bool separated = false;
-    V2 perp = mk(-normal.y, normal.x);
-    (void)perp;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        V2 n = vneg(pn[i]);
-        float s1 = vdot(n, vsub(pv[i], v1));
-        float s2 = vdot(n, vsub(pv[i], v2));
-        float s = fmin32(s1, s2);
-        if (s > radius) separated = true; // first such axis ends the search with "no collision"
-        // adjacency filter: lower == upper limit, so both branches test the same expression
-        bool skip = vdot(vsub(n, limit), normal) < -B2_ANGULAR_SLOP;
-        if (!separated && !skip && s > polySep) {
-            polyIndex = i;
-            polySep = s;
-        }
-    }
-    if (separated) return;
-    bool polyValid = polyIndex >= 0;
-    const float k_relativeTol = 0.98f, k_absoluteTol = 0.001f;
-    bool primaryIsPoly = polyValid && (polySep > k_relativeTol * edgeSep + k_absoluteTol);
-    ClipV ie[2];
-    int rf_i1, rf_i2;
-    V2 rf_v1, rf_v2, rf_normal;
-    if (!primaryIsPoly) {
-        m.type = MF_FACE_A;
-        int bestIndex = 0;
-        float bestValue = vdot(normal, pn[0]);
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            float value = vdot(normal, pn[i]);
-            if (value < bestValue) { bestValue = value; bestIndex = i; }
-        }
-        int i1 = bestIndex, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
-        ie[0].v = sel4(pv, i1); ie[0].iA = 0; ie[0].iB = i1; ie[0].tA = CF_FACE; ie[0].tB = CF_VERTEX;
-        ie[1].v = sel4(pv, i2); ie[1].iA = 0; ie[1].iB = i2; ie[1].tA = CF_FACE; ie[1].tB = CF_VERTEX;
-        if (front) { rf_i1 = 0; rf_i2 = 1; rf_v1 = v1; rf_v2 = v2; rf_normal = normal1; }
-        else { rf_i1 = 1; rf_i2 = 0; rf_v1 = v2; rf_v2 = v1; rf_normal = vneg(normal1); }
-    } else {
-        m.type = MF_FACE_B;
-        ie[0].v = v1; ie[0].iA = 0; ie[0].iB = polyIndex; ie[0].tA = CF_VERTEX; ie[0].tB = CF_FACE;
-        ie[1].v = v2; ie[1].iA = 0; ie[1].iB = polyIndex; ie[1].tA = CF_VERTEX; ie[1].tB = CF_FACE;
-        rf_i1 = polyIndex;
-        rf_i2 = rf_i1 + 1 < 4 ? rf_i1 + 1 : 0;
-        rf_v1 = sel4(pv, rf_i1);
-        rf_v2 = sel4(pv, rf_i2);
-        rf_normal = sel4(pn, rf_i1);
-    }
-    V2 sideNormal1 = mk(rf_normal.y, -rf_normal.x);
-    V2 sideNormal2 = vneg(sideNormal1);
-    float sideOffset1 = vdot(sideNormal1, rf_v1);
-    float sideOffset2 = vdot(sideNormal2, rf_v2);
-    ClipV c1[2], c2[2];
-    int np = clip_segment(c1, ie, sideNormal1, sideOffset1, rf_i1);
-    if (np < 2) return;
-    np = clip_segment(c2, c1, sideNormal2, sideOffset2, rf_i2);
-    if (np < 2) return;
-    if (!primaryIsPoly) {
-        m.ln = rf_normal;
-        m.lp = rf_v1;
-    } else {
-        m.ln = sel4(nloc, rf_i1);
-        m.lp = sel4(vloc, rf_i1);
-    }
-    int pointCount = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float separation = vdot(rf_normal, vsub(c2[i].v, rf_v1));
-        if (separation <= radius) {
-            V2 lp;
-            unsigned key;
-            if (!primaryIsPoly) {
-                lp = xmulT(q, p, c2[i].v);
-                key = mkkey(c2[i].iA, c2[i].iB, c2[i].tA, c2[i].tB);
-            } else {
-                lp = c2[i].v;
-                key = mkkey(c2[i].iB, c2[i].iA, c2[i].tB, c2[i].tA);
-            }
-            if (pointCount == 0) { m.p0 = lp; m.k0 = key; }
-            else { m.p1 = lp; m.k1 = key; }
-            ++pointCount;
-        }
-    }
-    m.count = pointCount;
-}
-
-// ---- hardcore terrain: static convex boxes (b2CollidePolygons, b2CollidePolygonAndCircle) ----
-DEV V2 static_vert(const Terrain &T, int s, int k) { return mk(T.vx[k * T.nStatic + s], T.vy[k * T.nStatic + s]); }
-DEV V2 static_normal(const Terrain &T, int s, int k) { return mk(T.nx[k * T.nStatic + s], T.ny[k * T.nStatic + s]); }
-struct Poly4 { V2 v[4]; V2 n[4]; };
-struct XFq { V2 p; Rot q; };
-DEV V2 xq_mul(const XFq &T, V2 v) { return xmul(T.q, T.p, v); }
-DEV V2 xq_mulT(const XFq &T, V2 v) { return xmulT(T.q, T.p, v); }
-DEV XFq xq_mulT_xf(const XFq &A, const XFq &B) { // b2MulT(A, B)
-    XFq C;
-    C.q.s = A.q.c * B.q.s - A.q.s * B.q.c;
-    C.q.c = A.q.c * B.q.c + A.q.s * B.q.s;
-    C.p = rmulT(A.q, vsub(B.p, A.p));
-    return C;
-}
-// b2FindMaxSeparation (2.3.1, exhaustive)
-DEV float find_max_separation(int &edgeIndex, const Poly4 &poly1, const XFq &xf1, const Poly4 &poly2, const XFq &xf2) {
-    XFq xf = xq_mulT_xf(xf2, xf1);
-    int bestIndex = 0;
-    float maxSeparation = -FLT_MAX;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        V2 n = rmul(xf.q, poly1.n[i]);
-        V2 v1 = xq_mul(xf, poly1.v[i]);
-        float si = FLT_MAX;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float sij = vdot(n, vsub(poly2.v[j], v1));
-            if (sij < si) si = sij;
-        }
-        if (si > maxSeparation) { maxSeparation = si; bestIndex = i; }
-    }
-    edgeIndex = bestIndex;
-    return maxSeparation;
-}
-// b2CollidePolygons(static box A at identity, module box B); flip rule of 2.3.1
-DEV void collide_polygons(Manifold &m, const Poly4 &polyA, const Poly4 &polyB, V2 pB, Rot qB) {
-    m.count = 0;
-    m.type = MF_FACE_A;
-    m.ln = mk(0.0f, 0.0f); m.lp = mk(0.0f, 0.0f); m.p0 = mk(0.0f, 0.0f); m.p1 = mk(0.0f, 0.0f);
-    m.k0 = m.k1 = 0u;
-    XFq xfA; xfA.p = mk(0.0f, 0.0f); xfA.q.s = 0.0f; xfA.q.c = 1.0f;
-    XFq xfB; xfB.p = pB; xfB.q = qB;
-    const float totalRadius = B2_POLYGON_RADIUS + B2_POLYGON_RADIUS;
-    int edgeA = 0;
-    float separationA = find_max_separation(edgeA, polyA, xfA, polyB, xfB);
-    if (separationA > totalRadius) return;
-    int edgeB = 0;
-    float separationB = find_max_separation(edgeB, polyB, xfB, polyA, xfA);
-    if (separationB > totalRadius) return;
-    const float k_tol = 0.1f * B2_LINEAR_SLOP;
-    const bool flip = separationB > separationA + k_tol;
-    const Poly4 &poly1 = flip ? polyB : polyA;
-    const Poly4 &poly2 = flip ? polyA : polyB;
-    const XFq xf1 = flip ? xfB : xfA, xf2 = flip ? xfA : xfB;
-    const int edge1 = flip ? edgeB : edgeA;
-    m.type = flip ? MF_FACE_B : MF_FACE_A;
-    // b2FindIncidentEdge
-    ClipV incident[2];
-    {
-        V2 normal1 = rmulT(xf2.q, rmul(xf1.q, sel4(poly1.n, edge1)));
-        int index = 0;
-        float minDot = FLT_MAX;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float dot = vdot(normal1, poly2.n[i]);
-            if (dot < minDot) { minDot = dot; index = i; }
-        }
-        int i1 = index, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
-        incident[0].v = xq_mul(xf2, sel4(poly2.v, i1)); incident[0].iA = edge1; incident[0].iB = i1; incident[0].tA = CF_FACE; incident[0].tB = CF_VERTEX;
-        incident[1].v = xq_mul(xf2, sel4(poly2.v, i2)); incident[1].iA = edge1; incident[1].iB = i2; incident[1].tA = CF_FACE; incident[1].tB = CF_VERTEX;
-    }
-    int iv1 = edge1, iv2 = edge1 + 1 < 4 ? edge1 + 1 : 0;
-    V2 v11 = sel4(poly1.v, iv1), v12 = sel4(poly1.v, iv2);
-    V2 localTangent = vsub(v12, v11);
-    vnormalize(localTangent);
-    V2 localNormal = vcross_vs(localTangent, 1.0f);
-    V2 planePoint = vscale(0.5f, vadd(v11, v12));
-    V2 tangent = rmul(xf1.q, localTangent);
-    V2 normal = vcross_vs(tangent, 1.0f);
-    v11 = xq_mul(xf1, v11);
-    v12 = xq_mul(xf1, v12);
-    float frontOffset = vdot(normal, v11);
-    float sideOffset1 = -vdot(tangent, v11) + totalRadius;
-    float sideOffset2 = vdot(tangent, v12) + totalRadius;
-    ClipV c1[2], c2[2];
-    int np = clip_segment(c1, incident, vneg(tangent), sideOffset1, iv1);
-    if (np < 2) return;
-    np = clip_segment(c2, c1, tangent, sideOffset2, iv2);
-    if (np < 2) return;
-    m.ln = localNormal;
-    m.lp = planePoint;
-    int pointCount = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float separation = vdot(normal, c2[i].v) - frontOffset;
-        if (separation <= totalRadius) {
-            V2 lp = xq_mulT(xf2, c2[i].v);
-            unsigned key = flip ? mkkey(c2[i].iB, c2[i].iA, c2[i].tB, c2[i].tA) : mkkey(c2[i].iA, c2[i].iB, c2[i].tA, c2[i].tB);
-            if (pointCount == 0) { m.p0 = lp; m.k0 = key; }
-            else { m.p1 = lp; m.k1 = key; }
-            ++pointCount;
-        }
-    }
-    m.count = pointCount;
-}
-// b2CollidePolygonAndCircle(static box A at identity, circle B with m_p = 0)
-DEV void collide_polygon_circle(Manifold &m, const Poly4 &polyA, float rB, V2 center) {
-    m.count = 0;
-    m.type = MF_FACE_A;
-    m.ln = mk(0.0f, 0.0f); m.lp = mk(0.0f, 0.0f); m.p0 = mk(0.0f, 0.0f); m.p1 = mk(0.0f, 0.0f);
-    m.k0 = m.k1 = 0u;
-    V2 cLocal = center;
-    int normalIndex = 0;
-    float separation = -FLT_MAX;
-    float radius = B2_POLYGON_RADIUS + rB;
-    bool out = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float s = vdot(polyA.n[i], vsub(cLocal, polyA.v[i]));
-        if (s > radius) out = true;
-        if (!out && s > separation) { separation = s; normalIndex = i; }
-    }
-    if (out) return;
-    int vertIndex1 = normalIndex, vertIndex2 = vertIndex1 + 1 < 4 ? vertIndex1 + 1 : 0;
-    V2 v1 = sel4(polyA.v, vertIndex1), v2 = sel4(polyA.v, vertIndex2);
-    if (separation < B2_EPSILON) {
-        m.count = 1;
-        m.ln = sel4(polyA.n, normalIndex);
-        m.lp = vscale(0.5f, vadd(v1, v2));
-        return;
-    }
-    float u1 = vdot(vsub(cLocal, v1), vsub(v2, v1));
-    float u2 = vdot(vsub(cLocal, v2), vsub(v1, v2));
-    if (u1 <= 0.0f) {
-        if (vdist2(cLocal, v1) > radius * radius) return;
-        m.count = 1;
-        m.ln = vsub(cLocal, v1);
-        vnormalize(m.ln);
-        m.lp = v1;
-    } else if (u2 <= 0.0f) {
-        if (vdist2(cLocal, v2) > radius * radius) return;
-        m.count = 1;
-        m.ln = vsub(cLocal, v2);
-        vnormalize(m.ln);
-        m.lp = v2;
-    } else {
-        V2 faceCenter = vscale(0.5f, vadd(v1, v2));
-        float sep = vdot(vsub(cLocal, faceCenter), sel4(polyA.n, vertIndex1));
-        if (sep > radius) return;
-        m.count = 1;
-        m.ln = sel4(polyA.n, vertIndex1);
-        m.lp = faceCenter;
-    }
-}
-DEV Poly4 static_poly(const Terrain &T, int s) {
-    Poly4 P;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { P.v[k] = static_vert(T, s, k); P.n[k] = static_normal(T, s, k); }
-    return P;
-}
-DEV Poly4 box_poly(float hx, float hy) {
-    Poly4 P;
-    P.v[0] = mk(-hx, -hy); P.v[1] = mk(hx, -hy); P.v[2] = mk(hx, hy); P.v[3] = mk(-hx, hy);
-    P.n[0] = mk(0.0f, -1.0f); P.n[1] = mk(1.0f, 0.0f); P.n[2] = mk(0.0f, 1.0f); P.n[3] = mk(-1.0f, 0.0f);
-    return P;
-}
-
-// =====================================================================================
-// shape AABBs (b2PolygonShape/b2CircleShape::ComputeAABB)
-// =====================================================================================
-struct AABB { V2 lo, hi; };
-DEV AABB body_aabb(int shape, float hx, float hy, V2 p, Rot q) {
-    AABB bb;
-    if (shape == SHAPE_BOX) {
-        V2 lower = xmul(q, p, mk(-hx, -hy)), upper = lower;
-        V2 v = xmul(q, p, mk(hx, -hy));
-        lower = vmin2(lower, v); upper = vmax2(upper, v);
-        v = xmul(q, p, mk(hx, hy));
-        lower = vmin2(lower, v); upper = vmax2(upper, v);
-        v = xmul(q, p, mk(-hx, hy));
-        lower = vmin2(lower, v); upper = vmax2(upper, v);
-        V2 r = mk(B2_POLYGON_RADIUS, B2_POLYGON_RADIUS);
-        bb.lo = vsub(lower, r);
-        bb.hi = vadd(upper, r);
-    } else {
-        V2 c = vadd(p, rmul(q, mk(0.0f, 0.0f)));
-        bb.lo = mk(c.x - hx, c.y - hx);
-        bb.hi = mk(c.x + hx, c.y + hx);
-    }
-    return bb;
-}
-DEV bool aabb_overlap(V2 alo, V2 ahi, V2 blo, V2 bhi) {
-    V2 d1 = vsub(blo, ahi), d2 = vsub(alo, bhi);
-    if (d1.x > 0.0f || d1.y > 0.0f) return false;
-    if (d2.x > 0.0f || d2.y > 0.0f) return false;
-    return true;
-}
-
-// =====================================================================================
-// per-lane solver structures (registers)
-// =====================================================================================
-struct ContactC { // one touching contact (terrain A static, body B = this lane)
-    V2 normal;
-    V2 rB0, rB1;
-    float nm0, nm1, tm0, tm1; // normalMass / tangentMass per point
-    float n0, n1, t0, t1;     // accumulated impulses
-    float k11, k12, k22;      // K
-    float i11, i12, i22;      // normalMass = K^-1 (symmetric)
-    int count;                // solver point count (block solver may drop to 1)
-};
-#define CC_WORDS 21
-
-// b2ContactManager::AddPair: head-insert into the body's pair list
-DEV void pairs_insert_front(const State &S, unsigned gl, int &count, int edge, int &err) {
-    if (count >= KC) { err |= REM2D_ERR_PAIR_OVERFLOW; return; }
-    for (int s = count; s > 0; --s) {
-        unsigned d = (unsigned)s * S.Lp + gl, f = (unsigned)(s - 1) * S.Lp + gl;
-        CI(C_EDGE, d) = CI(C_EDGE, f);
-        CI(C_INFO, d) = CI(C_INFO, f);
-        CU(C_KEY0, d) = CU(C_KEY0, f);
-        CU(C_KEY1, d) = CU(C_KEY1, f);
-        CF(C_N0, d) = CF(C_N0, f);
-        CF(C_N1, d) = CF(C_N1, f);
-        CF(C_T0, d) = CF(C_T0, f);
-        CF(C_T1, d) = CF(C_T1, f);
-    }
-    CI(C_EDGE, gl) = edge;
-    CI(C_INFO, gl) = 1 << 16; // e_enabledFlag (CI_ENABLED)
-    CU(C_KEY0, gl) = 0u;
-    CU(C_KEY1, gl) = 0u;
-    CF(C_N0, gl) = 0.0f;
-    CF(C_N1, gl) = 0.0f;
-    CF(C_T0, gl) = 0.0f;
-    CF(C_T1, gl) = 0.0f;
-    ++count;
-}
-DEV void pairs_remove(const State &S, unsigned gl, int &count, int s) {
-    for (int k = s; k + 1 < count; ++k) {
-        unsigned d = (unsigned)k * S.Lp + gl, f = (unsigned)(k + 1) * S.Lp + gl;
-        CI(C_EDGE, d) = CI(C_EDGE, f);
-        CI(C_INFO, d) = CI(C_INFO, f);
-        CU(C_KEY0, d) = CU(C_KEY0, f);
-        CU(C_KEY1, d) = CU(C_KEY1, f);
-        CF(C_N0, d) = CF(C_N0, f);
-        CF(C_N1, d) = CF(C_N1, f);
-        CF(C_T0, d) = CF(C_T0, f);
-        CF(C_T1, d) = CF(C_T1, f);
-    }
-    --count;
-    CI(C_EDGE, (unsigned)count * S.Lp + gl) = -1;
-}
-// b2BroadPhase::UpdatePairs for one moved body proxy: new pairs in ascending edge (= proxy id) order
-DEV bool find_new_pairs(const State &S, const Terrain &T, unsigned gl, int &count, V2 flo, V2 fhi, int &err) {
-    bool added = false;
-    for (int st = 0; st < T.nPoly; ++st) { // hardcore boxes have the lowest proxy ids
-        if (!aabb_overlap(mk(T.flx[st], T.fly[st]), mk(T.fux[st], T.fuy[st]), flo, fhi)) continue;
-        bool exists = false;
-        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == st);
-        if (!exists) {
-            pairs_insert_front(S, gl, count, st, err);
-            added = true;
-        }
-    }
-    int lo = (int)floorf((flo.x - 0.25f - T.x0) * T.invPitch) - 1;
-    int hi = (int)floorf((fhi.x + 0.25f - T.x0) * T.invPitch) + 1;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > T.nEdge - 1 ? T.nEdge - 1 : hi;
-    for (int e = lo; e <= hi; ++e) {
-        const int st = T.nPoly + e;
-        if (!aabb_overlap(mk(T.flx[st], T.fly[st]), mk(T.fux[st], T.fuy[st]), flo, fhi)) continue;
-        bool exists = false;
-        for (int s = 0; s < count; ++s) exists |= (CI(C_EDGE, (unsigned)s * S.Lp + gl) == st);
-        if (!exists) {
-            pairs_insert_front(S, gl, count, st, err);
-            added = true; // b2ContactManager::AddPair wakes both bodies
-        }
-    }
-    return added;
-}
-
-// ---- b2ContactSolver pieces for one (static terrain, this body) constraint ----
-// ctor + InitializeVelocityConstraints: b2WorldManifold with xfA = identity, radiusA = polygonRadius
-DEV void contact_setup(ContactC &c, int mtype, int mcount, V2 ln, V2 lp, V2 p0, V2 p1, V2 cB, Rot q, float mB, float iB,
-                       float radiusB, float n0, float t0, float n1, float t1) {
-    c.count = mcount;
-    c.n0 = n0; c.t0 = t0; c.n1 = n1; c.t1 = t1;
-    V2 normal, w0, w1 = mk(0.0f, 0.0f);
-    const float radiusA = B2_POLYGON_RADIUS;
-    if (mtype == MF_CIRCLES) {
-        normal = mk(1.0f, 0.0f);
-        V2 pointA = lp;
-        V2 pointB = xmul(q, cB, p0);
-        if (vdist2(pointA, pointB) > B2_EPSILON * B2_EPSILON) {
-            normal = vsub(pointB, pointA);
-            vnormalize(normal);
-        }
-        V2 cA = vadd(pointA, vscale(radiusA, normal));
-        V2 cBp = vsub(pointB, vscale(radiusB, normal));
-        w0 = vscale(0.5f, vadd(cA, cBp));
-    } else if (mtype == MF_FACE_A) {
-        normal = ln;
-        V2 planePoint = lp;
-        V2 clip = xmul(q, cB, p0);
-        V2 cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
-        V2 cBp = vsub(clip, vscale(radiusB, normal));
-        w0 = vscale(0.5f, vadd(cA, cBp));
-        if (mcount > 1) {
-            clip = xmul(q, cB, p1);
-            cA = vadd(clip, vscale(radiusA - vdot(vsub(clip, planePoint), normal), normal));
-            cBp = vsub(clip, vscale(radiusB, normal));
-            w1 = vscale(0.5f, vadd(cA, cBp));
-        }
-    } else {
-        V2 nB = rmul(q, ln);
-        V2 planePoint = xmul(q, cB, lp);
-        V2 clip = p0;
-        V2 cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
-        V2 cA = vsub(clip, vscale(radiusA, nB));
-        w0 = vscale(0.5f, vadd(cA, cBp));
-        if (mcount > 1) {
-            clip = p1;
-            cBp = vadd(clip, vscale(radiusB - vdot(vsub(clip, planePoint), nB), nB));
-            cA = vsub(clip, vscale(radiusA, nB));
-            w1 = vscale(0.5f, vadd(cA, cBp));
-        }
-        normal = vneg(nB);
-    }
-    c.normal = normal;
-    V2 tangent = vcross_vs(normal, 1.0f);
-    c.rB0 = vsub(w0, cB);
-    c.rB1 = vsub(w1, cB);
-    {
-        float rnB = vcross(c.rB0, normal);
-        float kNormal = mB + iB * rnB * rnB;
-        c.nm0 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-        float rtB = vcross(c.rB0, tangent);
-        float kTangent = mB + iB * rtB * rtB;
-        c.tm0 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-    }
-    c.nm1 = c.tm1 = 0.0f;
-    c.k11 = c.k12 = c.k22 = c.i11 = c.i12 = c.i22 = 0.0f;
-    if (mcount > 1) {
-        float rnB = vcross(c.rB1, normal);
-        float kNormal = mB + iB * rnB * rnB;
-        c.nm1 = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-        float rtB = vcross(c.rB1, tangent);
-        float kTangent = mB + iB * rtB * rtB;
-        c.tm1 = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-        float rn1B = vcross(c.rB0, normal), rn2B = vcross(c.rB1, normal);
-        float k11 = mB + iB * rn1B * rn1B;
-        float k22 = mB + iB * rn2B * rn2B;
-        float k12 = mB + iB * rn1B * rn2B;
-        const float k_maxConditionNumber = 1000.0f;
-        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
-            c.k11 = k11; c.k12 = k12; c.k22 = k22;
-            float det = k11 * k22 - k12 * k12;
-            if (det != 0.0f) det = 1.0f / det;
-            c.i11 = det * k22;
-            c.i12 = -det * k12;
-            c.i22 = det * k11;
-        } else {
-            c.count = 1;
-        }
-    }
-}
-// WarmStart
-DEV void contact_warm_start(const ContactC &c, float mB, float iB, float &vx, float &vy, float &w) {
-    V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
-    V2 P = vadd(vscale(c.n0, normal), vscale(c.t0, tangent));
-    w += iB * vcross(c.rB0, P);
-    vx += mB * P.x; vy += mB * P.y;
-    if (c.count > 1) {
-        P = vadd(vscale(c.n1, normal), vscale(c.t1, tangent));
-        w += iB * vcross(c.rB1, P);
-        vx += mB * P.x; vy += mB * P.y;
-    }
-}
-// SolveVelocityConstraints for one contact (friction first, then normal / 2-point block LCP)
-DEV void contact_solve(ContactC &c, float mB, float iB, float friction, float &vx, float &vy, float &w) {
-    V2 normal = c.normal, tangent = vcross_vs(normal, 1.0f);
-    V2 vB = mk(vx, vy);
-    float wB = w;
-    {
-        V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
-        float vt = vdot(dv, tangent) - 0.0f;
-        float lambda = c.tm0 * (-vt);
-        float maxFriction = friction * c.n0;
-        float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
-        lambda = newImpulse - c.t0;
-        c.t0 = newImpulse;
-        V2 P = vscale(lambda, tangent);
-        vB = vadd(vB, vscale(mB, P));
-        wB += iB * vcross(c.rB0, P);
-    }
-    if (c.count > 1) {
-        V2 dv = vadd(vB, vcross_sv(wB, c.rB1));
-        float vt = vdot(dv, tangent) - 0.0f;
-        float lambda = c.tm1 * (-vt);
-        float maxFriction = friction * c.n1;
-        float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
-        lambda = newImpulse - c.t1;
-        c.t1 = newImpulse;
-        V2 P = vscale(lambda, tangent);
-        vB = vadd(vB, vscale(mB, P));
-        wB += iB * vcross(c.rB1, P);
-    }
-    if (c.count == 1) {
-        V2 dv = vadd(vB, vcross_sv(wB, c.rB0));
-        float vn = vdot(dv, normal);
-        float lambda = -c.nm0 * (vn - 0.0f);
-        float newImpulse = fmax32(c.n0 + lambda, 0.0f);
-        lambda = newImpulse - c.n0;
-        c.n0 = newImpulse;
-        V2 P = vscale(lambda, normal);
-        vB = vadd(vB, vscale(mB, P));
-        wB += iB * vcross(c.rB0, P);
-    } else {
-        V2 a = mk(c.n0, c.n1);
-        V2 dv1 = vadd(vB, vcross_sv(wB, c.rB0));
-        V2 dv2 = vadd(vB, vcross_sv(wB, c.rB1));
-        float vn1 = vdot(dv1, normal), vn2 = vdot(dv2, normal);
-        V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
-        b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
-        V2 x;
-        bool solved = false;
-        x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y)); // case 1
-        solved = x.x >= 0.0f && x.y >= 0.0f;
-        if (!solved) { // case 2
-            x.x = -c.nm0 * b.x;
-            x.y = 0.0f;
-            vn2 = c.k12 * x.x + b.y;
-            solved = x.x >= 0.0f && vn2 >= 0.0f;
-        }
-        if (!solved) { // case 3
-            x.x = 0.0f;
-            x.y = -c.nm1 * b.y;
-            vn1 = c.k12 * x.y + b.x;
-            solved = x.y >= 0.0f && vn1 >= 0.0f;
-        }
-        if (!solved) { // case 4
-            x.x = 0.0f;
-            x.y = 0.0f;
-            solved = b.x >= 0.0f && b.y >= 0.0f;
-        }
-        if (solved) {
-            V2 d = vsub(x, a);
-            V2 P1 = vscale(d.x, normal), P2 = vscale(d.y, normal);
-            vB = vadd(vB, vscale(mB, vadd(P1, P2)));
-            wB += iB * (vcross(c.rB0, P1) + vcross(c.rB1, P2));
-            c.n0 = x.x;
-            c.n1 = x.y;
-        }
-    }
-    vx = vB.x; vy = vB.y; w = wB;
-}
-// constraints beyond the register-resident ones live in handle scratch ([word][lane], coalesced)
-DEV void cc_store(const State &S, unsigned cb, const ContactC &c) {
-    SW(cb, 0) = c.normal.x; SW(cb, 1) = c.normal.y; SW(cb, 2) = c.rB0.x; SW(cb, 3) = c.rB0.y;
-    SW(cb, 4) = c.rB1.x; SW(cb, 5) = c.rB1.y; SW(cb, 6) = c.nm0; SW(cb, 7) = c.nm1; SW(cb, 8) = c.tm0;
-    SW(cb, 9) = c.tm1; SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
-    SW(cb, 14) = c.k11; SW(cb, 15) = c.k12; SW(cb, 16) = c.k22; SW(cb, 17) = c.i11; SW(cb, 18) = c.i12;
-    SW(cb, 19) = c.i22; SW(cb, 20) = __int_as_float(c.count);
-}
-DEV void cc_load(const State &S, unsigned cb, ContactC &c) {
-    c.normal = mk(SW(cb, 0), SW(cb, 1)); c.rB0 = mk(SW(cb, 2), SW(cb, 3)); c.rB1 = mk(SW(cb, 4), SW(cb, 5));
-    c.nm0 = SW(cb, 6); c.nm1 = SW(cb, 7); c.tm0 = SW(cb, 8); c.tm1 = SW(cb, 9);
-    c.n0 = SW(cb, 10); c.n1 = SW(cb, 11); c.t0 = SW(cb, 12); c.t1 = SW(cb, 13);
-    c.k11 = SW(cb, 14); c.k12 = SW(cb, 15); c.k22 = SW(cb, 16); c.i11 = SW(cb, 17); c.i12 = SW(cb, 18);
-    c.i22 = SW(cb, 19); c.count = __float_as_int(SW(cb, 20));
-}
-
-// =====================================================================================
-// continuous collision: b2Distance (GJK), b2TimeOfImpact, and the per-body TOI event loop of
-// b2World::SolveTOI.  Body A is always a static terrain shape (identity transform, time-
-// transparent sweep), body B this lane's module, so every body's TOI sequence is independent.
-// =====================================================================================
-struct XF { V2 p; Rot q; };
-DEV V2 xfmul(const XF &T, V2 v) { return xmul(T.q, T.p, v); }
-DEV XF xf_identity() { XF T; T.p = mk(0.0f, 0.0f); T.q.s = 0.0f; T.q.c = 1.0f; return T; }
-
-struct Proxy { V2 v[4]; int count; float radius; };
-DEV V2 pget(const Proxy &p, int i) { return sel4(p.v, i); }
-DEV int psupport(const Proxy &p, V2 d) {
-    int best = 0;
-    float bv = vdot(p.v[0], d);
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        if (i < p.count) {
-            float val = vdot(p.v[i], d);
-            if (val > bv) { best = i; bv = val; }
-        }
-    }
-    return best;
-}
-DEV Proxy proxy_edge(V2 a, V2 b) {
-    Proxy p; p.v[0] = a; p.v[1] = b; p.v[2] = mk(0.0f, 0.0f); p.v[3] = mk(0.0f, 0.0f); p.count = 2; p.radius = B2_POLYGON_RADIUS; return p;
-}
-DEV Proxy proxy_body(int shape, float hx, float hy) {
-    Proxy p;
-    if (shape == SHAPE_BOX) {
-        p.v[0] = mk(-hx, -hy); p.v[1] = mk(hx, -hy); p.v[2] = mk(hx, hy); p.v[3] = mk(-hx, hy); p.count = 4; p.radius = B2_POLYGON_RADIUS;
-    } else {
-        p.v[0] = mk(0.0f, 0.0f); p.v[1] = p.v[0]; p.v[2] = p.v[0]; p.v[3] = p.v[0]; p.count = 1; p.radius = hx;
-    }
-    return p;
-}
-struct SVtx { V2 wA, wB, w; float a; int iA, iB; };
-struct Simplex { SVtx v0, v1, v2; int count; };
-struct SCache { float metric; int count; int iA0, iA1, iA2, iB0, iB1, iB2; };
-
-DEV float simplex_metric(const Simplex &s) {
-    if (s.count == 2) return sqrtf(vdist2(s.v0.w, s.v1.w));
-    if (s.count == 3) return vcross(vsub(s.v1.w, s.v0.w), vsub(s.v2.w, s.v0.w));
-    return 0.0f;
-}
-DEV SVtx svtx_make(const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB, int iA, int iB, float a) {
-    SVtx v;
-    v.iA = iA; v.iB = iB;
-    v.wA = xfmul(xfA, pget(pA, iA));
-    v.wB = xfmul(xfB, pget(pB, iB));
-    v.w = vsub(v.wB, v.wA);
-    v.a = a;
-    return v;
-}
-DEV void simplex_read_cache(Simplex &s, const SCache &c, const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB) {
-    s.count = c.count;
-    s.v0 = svtx_make(pA, xfA, pB, xfB, c.count > 0 ? c.iA0 : 0, c.count > 0 ? c.iB0 : 0, 0.0f);
-    s.v1 = svtx_make(pA, xfA, pB, xfB, c.count > 1 ? c.iA1 : 0, c.count > 1 ? c.iB1 : 0, 0.0f);
-    s.v2 = svtx_make(pA, xfA, pB, xfB, c.count > 2 ? c.iA2 : 0, c.count > 2 ? c.iB2 : 0, 0.0f);
-    if (s.count > 1) {
-        float metric1 = c.metric;
-        float metric2 = simplex_metric(s);
-        if (metric2 < 0.5f * metric1 || 2.0f * metric1 < metric2 || metric2 < B2_EPSILON) s.count = 0;
-    }
-    if (s.count == 0) {
-        s.v0 = svtx_make(pA, xfA, pB, xfB, 0, 0, 1.0f);
-        s.count = 1;
-    }
-}
-DEV void simplex_write_cache(const Simplex &s, SCache &c) {
-    c.metric = simplex_metric(s);
-    c.count = s.count;
-    c.iA0 = s.v0.iA; c.iB0 = s.v0.iB;
-    c.iA1 = s.v1.iA; c.iB1 = s.v1.iB;
-    c.iA2 = s.v2.iA; c.iB2 = s.v2.iB;
-}
-DEV void simplex_solve2(Simplex &s) {
-    V2 w1 = s.v0.w, w2 = s.v1.w;
-    V2 e12 = vsub(w2, w1);
-    float d12_2 = -vdot(w1, e12);
-    if (d12_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
-    float d12_1 = vdot(w2, e12);
-    if (d12_1 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
-    float inv_d12 = 1.0f / (d12_1 + d12_2);
-    s.v0.a = d12_1 * inv_d12;
-    s.v1.a = d12_2 * inv_d12;
-    s.count = 2;
-}
-DEV void simplex_solve3(Simplex &s) {
-    V2 w1 = s.v0.w, w2 = s.v1.w, w3 = s.v2.w;
-    V2 e12 = vsub(w2, w1);
-    float w1e12 = vdot(w1, e12), w2e12 = vdot(w2, e12);
-    float d12_1 = w2e12, d12_2 = -w1e12;
-    V2 e13 = vsub(w3, w1);
-    float w1e13 = vdot(w1, e13), w3e13 = vdot(w3, e13);
-    float d13_1 = w3e13, d13_2 = -w1e13;
-    V2 e23 = vsub(w3, w2);
-    float w2e23 = vdot(w2, e23), w3e23 = vdot(w3, e23);
-    float d23_1 = w3e23, d23_2 = -w2e23;
-    float n123 = vcross(e12, e13);
-    float d123_1 = n123 * vcross(w2, w3);
-    float d123_2 = n123 * vcross(w3, w1);
-    float d123_3 = n123 * vcross(w1, w2);
-    if (d12_2 <= 0.0f && d13_2 <= 0.0f) { s.v0.a = 1.0f; s.count = 1; return; }
-    if (d12_1 > 0.0f && d12_2 > 0.0f && d123_3 <= 0.0f) {
-        float inv_d12 = 1.0f / (d12_1 + d12_2);
-        s.v0.a = d12_1 * inv_d12; s.v1.a = d12_2 * inv_d12; s.count = 2; return;
-    }
-    if (d13_1 > 0.0f && d13_2 > 0.0f && d123_2 <= 0.0f) {
-        float inv_d13 = 1.0f / (d13_1 + d13_2);
-        s.v0.a = d13_1 * inv_d13; s.v2.a = d13_2 * inv_d13; s.count = 2; s.v1 = s.v2; return;
-    }
-    if (d12_1 <= 0.0f && d23_2 <= 0.0f) { s.v1.a = 1.0f; s.count = 1; s.v0 = s.v1; return; }
-    if (d13_1 <= 0.0f && d23_1 <= 0.0f) { s.v2.a = 1.0f; s.count = 1; s.v0 = s.v2; return; }
-    if (d23_1 > 0.0f && d23_2 > 0.0f && d123_1 <= 0.0f) {
-        float inv_d23 = 1.0f / (d23_1 + d23_2);
-        s.v1.a = d23_1 * inv_d23; s.v2.a = d23_2 * inv_d23; s.count = 2; s.v0 = s.v2; return;
-    }
-    float inv_d123 = 1.0f / (d123_1 + d123_2 + d123_3);
-    s.v0.a = d123_1 * inv_d123; s.v1.a = d123_2 * inv_d123; s.v2.a = d123_3 * inv_d123; s.count = 3;
-}
-// b2Distance with useRadii = false; returns the distance between the core shapes
-DEV float gjk_distance(SCache &cache, const Proxy &pA, const XF &xfA, const Proxy &pB, const XF &xfB) {
-    Simplex s;
-    simplex_read_cache(s, cache, pA, xfA, pB, xfB);
-    int iter = 0;
-    while (iter < 20) {
-        int saveCount = s.count;
-        int sA0 = s.v0.iA, sB0 = s.v0.iB, sA1 = s.v1.iA, sB1 = s.v1.iB, sA2 = s.v2.iA, sB2 = s.v2.iB;
-        if (s.count == 2) simplex_solve2(s);
-        else if (s.count == 3) simplex_solve3(s);
-        if (s.count == 3) break;
-        // search direction
-        V2 d;
-        if (s.count == 1) d = vneg(s.v0.w);
-        else {
-            V2 e12 = vsub(s.v1.w, s.v0.w);
-            float sgn = vcross(e12, vneg(s.v0.w));
-            d = sgn > 0.0f ? vcross_sv(1.0f, e12) : vcross_vs(e12, 1.0f);
-        }
-        if (vdot(d, d) < B2_EPSILON * B2_EPSILON) break;
-        int iA = psupport(pA, rmulT(xfA.q, vneg(d)));
-        int iB = psupport(pB, rmulT(xfB.q, d));
-        SVtx nv = svtx_make(pA, xfA, pB, xfB, iA, iB, 0.0f);
-        // vertices[count] = nv (a is left as it was in Box2D: stale; it is overwritten by the next Solve)
-        if (s.count == 1) { nv.a = s.v1.a; s.v1 = nv; } else { nv.a = s.v2.a; s.v2 = nv; }
-        ++iter;
-        bool duplicate = (saveCount > 0 && iA == sA0 && iB == sB0) || (saveCount > 1 && iA == sA1 && iB == sB1) ||
-                         (saveCount > 2 && iA == sA2 && iB == sB2);
-        if (duplicate) break;
-        ++s.count;
-    }
-    V2 pointA, pointB;
-    if (s.count == 1) { pointA = s.v0.wA; pointB = s.v0.wB; }
-    else if (s.count == 2) {
-        pointA = vadd(vscale(s.v0.a, s.v0.wA), vscale(s.v1.a, s.v1.wA));
-        pointB = vadd(vscale(s.v0.a, s.v0.wB), vscale(s.v1.a, s.v1.wB));
-    } else {
-        pointA = vadd(vadd(vscale(s.v0.a, s.v0.wA), vscale(s.v1.a, s.v1.wA)), vscale(s.v2.a, s.v2.wA));
-        pointB = pointA;
-    }
-    simplex_write_cache(s, cache);
-    return sqrtf(vdist2(pointA, pointB));
-}
-
-struct Sweep { V2 c0, c; float a0, a; };
-DEV XF sweep_xf(const Sweep &s, float beta) {
-    XF T;
-    T.p = vadd(vscale(1.0f - beta, s.c0), vscale(beta, s.c));
-    float angle = (1.0f - beta) * s.a0 + beta * s.a;
-    T.q = rot_set(angle);
-    T.p = vsub(T.p, rmul(T.q, mk(0.0f, 0.0f)));
-    return T;
-}
-enum { SEP_POINTS = 0, SEP_FACE_A = 1, SEP_FACE_B = 2 };
-struct SepFn { int type; V2 localPoint, axis; };
-DEV void sepfn_init(SepFn &f, const SCache &cache, const Proxy &pA, const Proxy &pB, const Sweep &sB, float t1) {
-    XF xfA = xf_identity(), xfB = sweep_xf(sB, t1);
-    f.localPoint = mk(0.0f, 0.0f);
-    if (cache.count == 1) {
-        f.type = SEP_POINTS;
-        V2 pointA = xfmul(xfA, pget(pA, cache.iA0)), pointB = xfmul(xfB, pget(pB, cache.iB0));
-        f.axis = vsub(pointB, pointA);
-        vnormalize(f.axis);
-    } else if (cache.iA0 == cache.iA1) {
-        f.type = SEP_FACE_B;
-        V2 lB1 = pget(pB, cache.iB0), lB2 = pget(pB, cache.iB1);
-        f.axis = vcross_vs(vsub(lB2, lB1), 1.0f);
-        vnormalize(f.axis);
-        V2 normal = rmul(xfB.q, f.axis);
-        f.localPoint = vscale(0.5f, vadd(lB1, lB2));
-        V2 pointB = xfmul(xfB, f.localPoint);
-        V2 pointA = xfmul(xfA, pget(pA, cache.iA0));
-        float s = vdot(vsub(pointA, pointB), normal);
-        if (s < 0.0f) f.axis = vneg(f.axis);
-    } else {
-        f.type = SEP_FACE_A;
-        V2 lA1 = pget(pA, cache.iA0), lA2 = pget(pA, cache.iA1);
-        f.axis = vcross_vs(vsub(lA2, lA1), 1.0f);
-        vnormalize(f.axis);
-        V2 normal = rmul(xfA.q, f.axis);
-        f.localPoint = vscale(0.5f, vadd(lA1, lA2));
-        V2 pointA = xfmul(xfA, f.localPoint);
-        V2 pointB = xfmul(xfB, pget(pB, cache.iB0));
-        float s = vdot(vsub(pointB, pointA), normal);
-        if (s < 0.0f) f.axis = vneg(f.axis);
-    }
-}
-DEV float sepfn_find_min(const SepFn &f, const Proxy &pA, const Proxy &pB, const Sweep &sB, int &indexA, int &indexB, float t) {
-    XF xfA = xf_identity(), xfB = sweep_xf(sB, t);
-    if (f.type == SEP_POINTS) {
-        V2 axisA = rmulT(xfA.q, f.axis);
-        V2 axisB = rmulT(xfB.q, vneg(f.axis));
-        indexA = psupport(pA, axisA);
-        indexB = psupport(pB, axisB);
-        V2 pointA = xfmul(xfA, pget(pA, indexA)), pointB = xfmul(xfB, pget(pB, indexB));
-        return vdot(vsub(pointB, pointA), f.axis);
-    } else if (f.type == SEP_FACE_A) {
-        V2 normal = rmul(xfA.q, f.axis);
-        V2 pointA = xfmul(xfA, f.localPoint);
-        V2 axisB = rmulT(xfB.q, vneg(normal));
-        indexA = -1;
-        indexB = psupport(pB, axisB);
-        V2 pointB = xfmul(xfB, pget(pB, indexB));
-        return vdot(vsub(pointB, pointA), normal);
-    } else {
-        V2 normal = rmul(xfB.q, f.axis);
-        V2 pointB = xfmul(xfB, f.localPoint);
-        V2 axisA = rmulT(xfA.q, vneg(normal));
-        indexB = -1;
-        indexA = psupport(pA, axisA);
-        V2 pointA = xfmul(xfA, pget(pA, indexA));
-        return vdot(vsub(pointA, pointB), normal);
-    }
-}
-DEV float sepfn_evaluate(const SepFn &f, const Proxy &pA, const Proxy &pB, const Sweep &sB, int indexA, int indexB, float t) {
-    XF xfA = xf_identity(), xfB = sweep_xf(sB, t);
-    if (f.type == SEP_POINTS) {
-        V2 pointA = xfmul(xfA, pget(pA, indexA)), pointB = xfmul(xfB, pget(pB, indexB));
-        return vdot(vsub(pointB, pointA), f.axis);
-    } else if (f.type == SEP_FACE_A) {
-        V2 normal = rmul(xfA.q, f.axis);
-        V2 pointA = xfmul(xfA, f.localPoint);
-        V2 pointB = xfmul(xfB, pget(pB, indexB));
-        return vdot(vsub(pointB, pointA), normal);
-    } else {
-        V2 normal = rmul(xfB.q, f.axis);
-        V2 pointB = xfmul(xfB, f.localPoint);
-        V2 pointA = xfmul(xfA, pget(pA, indexA));
-        return vdot(vsub(pointA, pointB), normal);
-    }
-}
-enum { TOI_UNKNOWN = 0, TOI_FAILED, TOI_OVERLAPPED, TOI_TOUCHING, TOI_SEPARATED };
-// b2TimeOfImpact(static A, swept B, tMax = 1)
-DEV void time_of_impact(int &state, float &tOut, const Proxy &pA, const Proxy &pB, Sweep sB) {
-    state = TOI_UNKNOWN;
-    const float tMax = 1.0f;
-    tOut = tMax;
-    { // b2Sweep::Normalize
-        float twoPi = 2.0f * B2_PI;
-        float d = twoPi * floorf(sB.a0 / twoPi);
-        sB.a0 -= d;
-        sB.a -= d;
-    }
-    float totalRadius = pA.radius + pB.radius;
-    float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
-    float tolerance = 0.25f * B2_LINEAR_SLOP;
-    float t1 = 0.0f;
-    int iter = 0;
-    SCache cache;
-    cache.metric = 0.0f; cache.count = 0; cache.iA0 = cache.iA1 = cache.iA2 = cache.iB0 = cache.iB1 = cache.iB2 = 0;
-    for (;;) {
-        XF xfA = xf_identity(), xfB = sweep_xf(sB, t1);
-        float distance = gjk_distance(cache, pA, xfA, pB, xfB);
-        if (distance <= 0.0f) { state = TOI_OVERLAPPED; tOut = 0.0f; break; }
-        if (distance < target + tolerance) { state = TOI_TOUCHING; tOut = t1; break; }
-        SepFn fcn;
-        sepfn_init(fcn, cache, pA, pB, sB, t1);
-        bool done = false;
-        float t2 = tMax;
-        int pushBackIter = 0;
-        for (;;) {
-            int indexA, indexB;
-            float s2 = sepfn_find_min(fcn, pA, pB, sB, indexA, indexB, t2);
-            if (s2 > target + tolerance) { state = TOI_SEPARATED; tOut = tMax; done = true; break; }
-            if (s2 > target - tolerance) { t1 = t2; break; }
-            float s1 = sepfn_evaluate(fcn, pA, pB, sB, indexA, indexB, t1);
-            if (s1 < target - tolerance) { state = TOI_FAILED; tOut = t1; done = true; break; }
-            if (s1 <= target + tolerance) { state = TOI_TOUCHING; tOut = t1; done = true; break; }
-            int rootIterCount = 0;
-            float a1 = t1, a2 = t2;
-            for (;;) {
-                float t;
-                if (rootIterCount & 1) t = a1 + (target - s1) * (a2 - a1) / (s2 - s1);
-                else t = 0.5f * (a1 + a2);
-                ++rootIterCount;
-                float s = sepfn_evaluate(fcn, pA, pB, sB, indexA, indexB, t);
-                if (fabs32(s - target) < tolerance) { t2 = t; break; }
-                if (s > target) { a1 = t; s1 = s; } else { a2 = t; s2 = s; }
-                if (rootIterCount == 50) break;
-            }
-            ++pushBackIter;
-            if (pushBackIter == 8) break;
-        }
-        ++iter;
-        if (done) break;
-        if (iter == 20) { state = TOI_FAILED; tOut = t1; break; }
-    }
-}
-
-// pair-slot info word: bits 0-7 manifold point count, 8-15 manifold type, then b2Contact flags
-#define CI_COUNT(i) ((i) & 0xff)
-#define CI_TYPE(i) (((i) >> 8) & 0xff)
-#define CI_ENABLED (1 << 16)
-#define CI_TOIFLAG (1 << 17)
-#define CI_ISLAND (1 << 18)
-#define CI_TOICOUNT_SHIFT 20
-#define CI_TOICOUNT(i) (((i) >> CI_TOICOUNT_SHIFT) & 0x1f)
-#define CI_KEEP_MASK (~0xffff) // flag bits survive a manifold update
-
-// b2Contact::Update for pair slot o32 of this lane at body transform (p, q): narrowphase, carry the
-// warm-start impulses over by feature id, store.  Returns the new manifold.
-DEV void contact_update_slot(const State &S, const Terrain &T, unsigned o, int shape, float hx, float hy, V2 p, Rot q,
-                             Manifold &m, bool sleepResetAlways, float &sleepT) {
-    int e = CI(C_EDGE, o); // static proxy index: hardcore boxes first, then edges
-    if (e < T.nPoly) {
-        Poly4 PA = static_poly(T, e);
-        if (shape == SHAPE_BOX) collide_polygons(m, PA, box_poly(hx, hy), p, q);
-        else collide_polygon_circle(m, PA, hx, p);
-    } else {
-        V2 e1 = static_vert(T, e, 0), e2 = static_vert(T, e, 1);
-        if (shape == SHAPE_BOX) collide_edge_box(m, e1, e2, hx, hy, p, q);
-        else collide_edge_circle(m, e1, e2, hx, p);
-    }
-    int info = CI(C_INFO, o);
-    int oldCount = CI_COUNT(info);
-    if (((m.count > 0) != (oldCount > 0)) && sleepResetAlways) sleepT = 0.0f; // touching changed -> SetAwake
-    unsigned ok0 = CU(C_KEY0, o), ok1 = CU(C_KEY1, o);
-    float on0 = CF(C_N0, o), on1 = CF(C_N1, o), ot0 = CF(C_T0, o), ot1 = CF(C_T1, o);
-    float n0 = 0.0f, t0 = 0.0f, n1 = 0.0f, t1 = 0.0f;
-    if (m.count > 0) {
-        if (oldCount > 0 && ok0 == m.k0) { n0 = on0; t0 = ot0; }
-        else if (oldCount > 1 && ok1 == m.k0) { n0 = on1; t0 = ot1; }
-    }
-    if (m.count > 1) {
-        if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
-        else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
-    }
-    CI(C_INFO, o) = (info & CI_KEEP_MASK) | CI_ENABLED | m.count | (m.type << 8);
-    CU(C_KEY0, o) = m.k0;
-    CU(C_KEY1, o) = m.k1;
-    CF(C_N0, o) = n0;
-    CF(C_N1, o) = n1;
-    CF(C_T0, o) = t0;
-    CF(C_T1, o) = t1;
-}
-DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
-    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
-    SW(sb, 0) = __int_as_float(m.type | (m.count << 8));
-    SW(sb, 1) = m.ln.x; SW(sb, 2) = m.ln.y; SW(sb, 3) = m.lp.x; SW(sb, 4) = m.lp.y;
-    SW(sb, 5) = m.p0.x; SW(sb, 6) = m.p0.y; SW(sb, 7) = m.p1.x; SW(sb, 8) = m.p1.y;
-}
-// scratch word offsets (per lane): manifolds [KT][SCR_WORDS], constraints [KT][CC_WORDS], TOI alphas [KC]
-#define SCR_CC_BASE (KT * SCR_WORDS)
-#define SCR_TOI_BASE (KT * SCR_WORDS + KT * CC_WORDS)
-#define SCR_SWEEP_BASE (SCR_TOI_BASE + KC) // c0.x, c0.y, a0 handed from the step kernel to the TOI kernel
-#define SCR_TOTAL_WORDS (SCR_SWEEP_BASE + 3)
-
-struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, events; };
-
-// b2World::SolveTOI restricted to this lane's body (see the section comment above).
-DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int shape, float hx, float hy, float mB, float iB,
-                                                float h, int velIters, float c0x, float c0y, float a0, LaneBody B) {
-    const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
-    const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
-    const float friction = T.friction;
-    const unsigned Lp = S.Lp;
-    // m_stepComplete is always true at this point: invalidate TOIs
-    float alpha0 = 0.0f;
-    Sweep sw;
-    sw.c0 = mk(c0x, c0y); sw.c = mk(B.px, B.py); sw.a0 = a0; sw.a = B.ang;
-    for (int s = 0; s < B.cCount; ++s) {
-        unsigned o = (unsigned)s * Lp + gl;
-        CI(C_INFO, o) = CI(C_INFO, o) & (0xffff | CI_ENABLED);
-    }
-    const Proxy pB = proxy_body(shape, hx, hy);
-    const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f; // circumradius of the core shape
-    for (;;) {
-        int minSlot = -1;
-        float minAlpha = 1.0f;
-        for (int s = 0; s < B.cCount; ++s) {
-            unsigned o = (unsigned)s * Lp + gl;
-            int info = CI(C_INFO, o);
-            if (!(info & CI_ENABLED)) continue;
-            if (CI_TOICOUNT(info) > 8) continue;
-            float alpha = 1.0f;
-            if (info & CI_TOIFLAG) {
-                alpha = SW((unsigned)(SCR_TOI_BASE + s) * Lp + gl, 0);
-            } else {
-                if (!B.awake) continue;
-                int e = CI(C_EDGE, o);
-                Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
-                if (e < T.nPoly) { pA.v[2] = static_vert(T, e, 2); pA.v[3] = static_vert(T, e, 3); pA.count = 4; }
-                // Conservative exact skip.  b2TimeOfImpact can only answer e_touching if some core-shape
-                // distance / separation it evaluates for t in [0,1] falls below target + tolerance, and every
-                // such value is >= the true distance of the core shapes at that t.  The body's core stays inside
-                // the disk of radius coreR around its centre, which moves on the segment c0 -> c: if that
-                // capsule's bounding box keeps more than target + tolerance (+ 5 mm for rounding) away from
-                // the static shape's bounding box, the answer is alpha = 1 without running GJK.
-                bool farApart;
-                {
-                    V2 slo = pA.v[0], shi = pA.v[0];
-#pragma unroll
-                    for (int k = 1; k < 4; ++k)
-                        if (k < pA.count) { slo = vmin2(slo, pA.v[k]); shi = vmax2(shi, pA.v[k]); }
-                    V2 blo = vsub(vmin2(sw.c0, sw.c), mk(coreR, coreR)), bhi = vadd(vmax2(sw.c0, sw.c), mk(coreR, coreR));
-                    float gap = fmax32(fmax32(blo.x - shi.x, slo.x - bhi.x), fmax32(blo.y - shi.y, slo.y - bhi.y));
-                    float totalRadius = pA.radius + pB.radius;
-                    float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
-                    const float need = target + 0.25f * B2_LINEAR_SLOP;
-                    farApart = gap > need + 0.005f;
-                    if (!farApart) {
-                        // Second bound (catches resting contacts): any separating axis gives a lower bound lb0 of the
-                        // core distance at the sweep start, and no point of the body moves further than
-                        // |c - c0| + coreR * |a - a0| during the sweep, so distance(t) >= lb0 - that.  Axes tried:
-                        // the static shape's face normals and the body's own axes.
-                        Rot q0 = rot_set(sw.a0);
-                        float lb0 = -FLT_MAX;
-                        V2 bv[4];
-                        const int nb = pB.count;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) bv[k] = xmul(q0, sw.c0, pB.v[k < nb ? k : 0]);
-                        if (pA.count == 2) { // edge: +-normal, and the edge direction beyond either end
-                            V2 e = vsub(pA.v[1], pA.v[0]);
-                            vnormalize(e);
-                            V2 n = mk(e.y, -e.x);
-                            float lo = FLT_MAX, hi = -FLT_MAX, tlo = FLT_MAX, thi = -FLT_MAX;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float d = vdot(n, vsub(bv[k], pA.v[0]));
-                                lo = fmin32(lo, d); hi = fmax32(hi, d);
-                                float td = vdot(e, vsub(bv[k], pA.v[0]));
-                                tlo = fmin32(tlo, td); thi = fmax32(thi, td);
-                            }
-                            float elen = vdot(e, vsub(pA.v[1], pA.v[0]));
-                            lb0 = fmax32(fmax32(lo, -hi), fmax32(tlo - elen, -thi));
-                        } else { // static box: its four face normals
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                V2 a = pA.v[i], b2 = pA.v[(i + 1) & 3];
-                                V2 ed = vsub(b2, a);
-                                vnormalize(ed);
-                                V2 n = mk(ed.y, -ed.x);
-                                float lo = FLT_MAX;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) lo = fmin32(lo, vdot(n, vsub(bv[k], a)));
-                                lb0 = fmax32(lb0, lo);
-                            }
-                        }
-                        if (shape == SHAPE_BOX) { // the body's axes against the static shape's vertices
-                            float xlo = FLT_MAX, xhi = -FLT_MAX, ylo = FLT_MAX, yhi = -FLT_MAX;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (k < pA.count) {
-                                    V2 l = rmulT(q0, vsub(pA.v[k], sw.c0));
-                                    xlo = fmin32(xlo, l.x); xhi = fmax32(xhi, l.x);
-                                    ylo = fmin32(ylo, l.y); yhi = fmax32(yhi, l.y);
-                                }
-                            }
-                            lb0 = fmax32(lb0, fmax32(fmax32(xlo - hx, -xhi - hx), fmax32(ylo - hy, -yhi - hy)));
-                        }
-                        float maxDisp = vlen(vsub(sw.c, sw.c0)) + coreR * fabs32(sw.a - sw.a0);
-                        farApart = lb0 - maxDisp > need + 0.002f;
-                    }
-                }
-                if (farApart) {
-                    alpha = 1.0f;
-                } else {
-                    int state;
-                    float t;
-                    time_of_impact(state, t, pA, pB, sw);
-                    float beta = t;
-                    if (state == TOI_TOUCHING) alpha = fmin32(alpha0 + (1.0f - alpha0) * beta, 1.0f);
-                    else alpha = 1.0f;
-                }
-                SW((unsigned)(SCR_TOI_BASE + s) * Lp + gl, 0) = alpha;
-                CI(C_INFO, o) = info | CI_TOIFLAG;
-            }
-            if (alpha < minAlpha) { minSlot = s; minAlpha = alpha; }
-        }
-        if (minSlot < 0 || 1.0f - 10.0f * B2_EPSILON < minAlpha) break;
-        // ---- advance the body to the TOI (b2Body::Advance) ----
-        const Sweep backup = sw;
-        const float backupAlpha0 = alpha0;
-        {
-            float beta = (minAlpha - alpha0) / (1.0f - alpha0);
-            sw.c0 = vadd(sw.c0, vscale(beta, vsub(sw.c, sw.c0)));
-            sw.a0 += beta * (sw.a - sw.a0);
-            alpha0 = minAlpha;
-            sw.c = sw.c0;
-            sw.a = sw.a0;
-        }
-        Rot q = rot_set(sw.a);
-        V2 p = vsub(sw.c, rmul(q, mk(0.0f, 0.0f)));
-        const unsigned om = (unsigned)minSlot * Lp + gl;
-        Manifold m;
-        contact_update_slot(S, T, om, shape, hx, hy, p, q, m, sleepResetAlways, B.sleepT);
-        {
-            int info = CI(C_INFO, om);
-            int cnt = CI_TOICOUNT(info) + 1;
-            info = (info & ~(CI_TOIFLAG | (0x1f << CI_TOICOUNT_SHIFT))) | (cnt << CI_TOICOUNT_SHIFT);
-            if (m.count == 0) info &= ~CI_ENABLED; // not solid: SetEnabled(false), restore the sweep
-            CI(C_INFO, om) = info;
-        }
-        if (m.count == 0) {
-            sw = backup;
-            alpha0 = backupAlpha0;
-            continue;
-        }
-        if (sleepResetAlways || !B.awake) B.sleepT = 0.0f;
-        B.awake = 1;
-        B.events += 1;
-        // ---- TOI island: this body, the TOI contact, then its other touching contacts (list order) ----
-        int nIsl = 0;
-        unsigned islPack = 0u;
-        manifold_store(S, gl, 0, m);
-        islPack |= (unsigned)minSlot;
-        nIsl = 1;
-        CI(C_INFO, om) = CI(C_INFO, om) | CI_ISLAND;
-        for (int s = 0; s < B.cCount; ++s) {
-            if (s == minSlot) continue;
-            unsigned o = (unsigned)s * Lp + gl;
-            Manifold mo;
-            contact_update_slot(S, T, o, shape, hx, hy, p, q, mo, sleepResetAlways, B.sleepT);
-            if (mo.count == 0) continue;
-            if (nIsl >= KT) { B.err |= REM2D_ERR_SOLVER_OVERFLOW; continue; }
-            manifold_store(S, gl, nIsl, mo);
-            islPack |= (unsigned)s << (5 * nIsl);
-            ++nIsl;
-        }
-        // ---- b2Island::SolveTOI ----
-        float cx = sw.c.x, cy = sw.c.y, ca = sw.a;
-        for (int it = 0; it < 20; ++it) { // SolveTOIPositionConstraints: only this body moves
-            float minSeparation = 0.0f;
-            for (int t = 0; t < nIsl; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
-                int mtype = tc & 0xff, mcount = tc >> 8;
-                V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
-                const float radiusA = B2_POLYGON_RADIUS;
-                for (int j = 0; j < mcount; ++j) {
-                    V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
-                    V2 cB = mk(cx, cy);
-                    V2 normal, point;
-                    float separation;
-                    Rot qB = rot_set(ca);
-                    if (mtype == MF_CIRCLES) {
-                        V2 pointA = lp;
-                        V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
-                        normal = vsub(pointB, pointA);
-                        vnormalize(normal);
-                        point = vscale(0.5f, vadd(pointA, pointB));
-                        separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                    } else if (mtype == MF_FACE_A) {
-                        normal = ln;
-                        V2 clipPoint = xmul(qB, cB, pj);
-                        separation = vdot(vsub(clipPoint, lp), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                    } else {
-                        normal = rmul(qB, ln);
-                        V2 planePoint = xmul(qB, cB, lp);
-                        V2 clipPoint = pj;
-                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                        normal = vneg(normal);
-                    }
-                    V2 rBp = vsub(point, cB);
-                    minSeparation = fmin32(minSeparation, separation);
-                    float C = fclamp(0.75f * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                    float rnB = vcross(rBp, normal);
-                    float Kn = mB + iB * rnB * rnB;
-                    float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                    V2 P = vscale(impulse, normal);
-                    cx = cx + mB * P.x;
-                    cy = cy + mB * P.y;
-                    ca += iB * vcross(rBp, P);
-                }
-            }
-            if (minSeparation >= -1.5f * B2_LINEAR_SLOP) break;
-        }
-        // leap of faith to the new safe state
-        sw.c0 = mk(cx, cy);
-        sw.a0 = ca;
-        // InitializeVelocityConstraints without warm starting, then velIters sweeps over the island contacts
-        // (the first KR constraints stay in registers, further ones -- rare -- go through scratch)
-        {
-            Rot qn = rot_set(ca);
-            ContactC tcc[KR];
-#pragma unroll
-            for (int t = 0; t < KR; ++t) {
-                tcc[t].count = 0;
-                if (t < nIsl) {
-                    const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                    int tc = __float_as_int(SW(sb, 0));
-                    contact_setup(tcc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
-                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f,
-                                  0.0f, 0.0f);
-                }
-            }
-            for (int t = KR; t < nIsl; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
-                ContactC c;
-                contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)), mk(SW(sb, 5), SW(sb, 6)),
-                              mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
-                cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
-            }
-            for (int it = 0; it < velIters; ++it) {
-                // Exact early exit: one sweep is a deterministic function of (velocity, impulses); a sweep
-                // that changes no bit is a fixed point, so every later sweep is the identity.  (Single-body
-                // contact-only systems reach it after ~10 sweeps; the full 180 are never needed.)
-                unsigned h0 = __float_as_uint(B.vx), h1 = __float_as_uint(B.vy), h2 = __float_as_uint(B.w);
-                bool changed = false;
-#pragma unroll
-                for (int t = 0; t < KR; ++t) {
-                    if (t < nIsl) {
-                        const unsigned a0 = __float_as_uint(tcc[t].n0), a1 = __float_as_uint(tcc[t].n1);
-                        const unsigned a2 = __float_as_uint(tcc[t].t0), a3 = __float_as_uint(tcc[t].t1);
-                        contact_solve(tcc[t], mB, iB, friction, B.vx, B.vy, B.w);
-                        changed |= a0 != __float_as_uint(tcc[t].n0) || a1 != __float_as_uint(tcc[t].n1) ||
-                                   a2 != __float_as_uint(tcc[t].t0) || a3 != __float_as_uint(tcc[t].t1);
-                    }
-                }
-                for (int t = KR; t < nIsl; ++t) {
-                    const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
-                    ContactC c;
-                    cc_load(S, cb, c);
-                    const unsigned a0 = __float_as_uint(c.n0), a1 = __float_as_uint(c.n1);
-                    const unsigned a2 = __float_as_uint(c.t0), a3 = __float_as_uint(c.t1);
-                    contact_solve(c, mB, iB, friction, B.vx, B.vy, B.w);
-                    changed |= a0 != __float_as_uint(c.n0) || a1 != __float_as_uint(c.n1) || a2 != __float_as_uint(c.t0) ||
-                               a3 != __float_as_uint(c.t1);
-                    SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
-                }
-                changed |= h0 != __float_as_uint(B.vx) || h1 != __float_as_uint(B.vy) || h2 != __float_as_uint(B.w);
-                if (!changed) break;
-            }
-        }
-        // integrate the remaining (1 - minAlpha) * dt; TOI impulses are not stored
-        {
-            float hs = (1.0f - minAlpha) * h;
-            V2 v = mk(B.vx, B.vy);
-            V2 translation = vscale(hs, v);
-            if (vdot(translation, translation) > B2_MAX_TRANSLATION_SQ) {
-                float ratio = B2_MAX_TRANSLATION / vlen(translation);
-                v = vscale(ratio, v);
-            }
-            float rotation = hs * B.w;
-            if (rotation * rotation > B2_MAX_ROTATION_SQ) {
-                float ratio = B2_MAX_ROTATION / fabs32(rotation);
-                B.w *= ratio;
-            }
-            cx = cx + hs * v.x;
-            cy = cy + hs * v.y;
-            ca += hs * B.w;
-            B.vx = v.x; B.vy = v.y;
-        }
-        sw.c = mk(cx, cy);
-        sw.a = ca;
-        // ---- reset flags, SynchronizeFixtures, FindNewContacts ----
-        for (int s = 0; s < B.cCount; ++s) {
-            unsigned o = (unsigned)s * Lp + gl;
-            CI(C_INFO, o) = CI(C_INFO, o) & ~(CI_TOIFLAG | CI_ISLAND);
-        }
-        {
-            Rot q0 = rot_set(sw.a0), q1 = rot_set(sw.a);
-            V2 p0 = vsub(sw.c0, rmul(q0, mk(0.0f, 0.0f)));
-            V2 p1 = vsub(sw.c, rmul(q1, mk(0.0f, 0.0f)));
-            AABB b1 = body_aabb(shape, hx, hy, p0, q0), b2 = body_aabb(shape, hx, hy, p1, q1);
-            V2 lo = vmin2(b1.lo, b2.lo), hi = vmax2(b1.hi, b2.hi);
-            V2 displacement = vsub(p1, p0);
-            V2 fatLo = mk(LF(L_FATLX), LF(L_FATLY)), fatHi = mk(LF(L_FATUX), LF(L_FATUY));
-            bool contains = fatLo.x <= lo.x && fatLo.y <= lo.y && hi.x <= fatHi.x && hi.y <= fatHi.y;
-            if (!contains) {
-                V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
-                V2 flo = vsub(lo, r), fhi = vadd(hi, r);
-                V2 d = vscale(B2_AABB_MULTIPLIER, displacement);
-                if (d.x < 0.0f) flo.x += d.x; else fhi.x += d.x;
-                if (d.y < 0.0f) flo.y += d.y; else fhi.y += d.y;
-                LF(L_FATLX) = flo.x; LF(L_FATLY) = flo.y; LF(L_FATUX) = fhi.x; LF(L_FATUY) = fhi.y;
-                if (find_new_pairs(S, T, gl, B.cCount, flo, fhi, B.err)) {
-                    if (sleepResetAlways || !B.awake) B.sleepT = 0.0f;
-                    B.awake = 1;
-                }
-            }
-        }
-    }
-    B.px = sw.c.x; B.py = sw.c.y; B.ang = sw.a;
-    return B;
-}
-
-// wod / reward / done (Modular2DEnv.py:613-614,642-649) and evaluate()'s fitness rule
-// (REM2D_main.py:362-377); executed by one lane per creature, once per env step.
-DEV void env_bookkeeping(const State &S, unsigned env, int sub, float rootx) {
-    if (sub != 0) return;
-    double wod = ED(E_WOD) + 0.04;
-    ED(E_WOD) = wod;
-    double r = (double)rootx;
-    double rew = r;
-    int d = 0;
-    if (r < 0.0) { rew = -100.0; d = 1; }
-    if (wod > r) { rew = -100.0; d = 1; }
-    EF(E_REWARD) = (float)rew;
-    EI(E_DONE) = d;
-    if (d) EI(E_EVERDONE) = 1;
-    int stepIdx = EI(E_STEPS);
-    if (!EI(E_FROZEN)) {
-        if (rew < -10.0) EI(E_FROZEN) = 1;
-        else if (rew > 100.0) { ED(E_FITNESS) = rew + (double)(10000 - stepIdx) / 10000.0; EI(E_FROZEN) = 1; }
-        else if (rew > 0.0) ED(E_FITNESS) = rew;
-    }
-    EI(E_STEPS) = stepIdx + 1;
-}
-
-// =====================================================================================
-// the step kernel
-// =====================================================================================
-struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ };
-
-// Register budget: what the 180-iteration velocity loop touches stays in VGPRs (body velocity,
-// joint effective-mass terms and impulses, KR contact constraints); everything else (pose
-// history, shape, fat AABB, anchors, controller, per-creature bookkeeping) is re-read from
-// HBM/L2 at its point of use once per step, so that the kernel fits two waves per SIMD.
-template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
-    const int lane = threadIdx.x;
-    const unsigned gl0 = blockIdx.x * WAVE + lane;
-    const unsigned env0 = gl0 / K;
-    unsigned gl = gl0, env = env0;
-    const int base = lane & ~(K - 1);
-    const int sub = lane & (K - 1);
-    const unsigned Lp = S.Lp;
-    // scratch: manifolds [KT][SCR_WORDS][Lp], then overflow constraints [KT-KR][CC_WORDS][Lp]
-
-    const int shape = LI(L_SHAPE);
-    const bool active = shape != SHAPE_NONE;
-    const float mB = LF(L_INVM), iB = LF(L_INVI);
-    float px = LF(L_PX), py = LF(L_PY), ang = LF(L_ANG), vx = LF(L_VX), vy = LF(L_VY), w = LF(L_W);
-    float sleepT = LF(L_SLEEPT);
-    int awake = LI(L_AWAKE);
-    int cCount = LI(L_CCOUNT);
-    const int parent = LI(L_PARENT);
-    const bool hasJoint = active && parent >= 0;
-    const int pl = base + (parent >= 0 ? parent : 0);
-    // packed schedule (compiler.pipeline_schedule): joint round | contact slot << 8 | period << 16
-    const int sched = LI(L_JROUND);
-    const int jround = hasJoint ? (sched & 0xff) : -1;
-    const int offC = (sched >> 8) & 0xff, period = (sched >> 16) & 0xff;
-    float impX = LF(L_JIMPX), impY = LF(L_JIMPY), impZ = LF(L_JIMPZ), motorImp = LF(L_JMOTORIMP);
-    int limitState = LI(L_JLIMIT);
-    float motorSpeed = LF(L_JMOTORSPEED);
-    const float mA = __shfl(mB, pl), iA = __shfl(iB, pl);
-    const int nRounds = wave_max(jround) + 1;
-    // bit b of childMask: some lane of this creature hangs off body b (K <= 64 -> two 32-bit halves)
-    const int childLo = group_or<K>((hasJoint && parent < 32) ? (1 << parent) : 0);
-    const int childHi = group_or<K>((hasJoint && parent >= 32) ? (1 << (parent - 32)) : 0);
-    const bool jointed = hasJoint || (((sub < 32 ? childLo >> sub : childHi >> (sub - 32))) & 1); // SetMotorSpeed wakes both bodies
-    float invDt0 = EF(E_INVDT0);
-    int newFix = EI(E_NEWFIX), err = 0, lastPosIters = EI(E_POSITERS);
-
-    const float h = A.dt;
-    const float inv_dt = h > 0.0f ? 1.0f / h : 0.0f;
-    const float friction = T.friction;
-    const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
-    const bool allowSleep = (S.flags & REM2D_FLAG_NO_SLEEP) == 0;
-
-    for (int step = 0; step < A.nSteps; ++step) {
-        // Launder the lane / creature offsets once per step: otherwise LLVM hoists every field's
-        // 64-bit address out of the step loop (60+ VGPR pairs) and then spills them.  With the
-        // offsets opaque per step, accesses select as global_load/store vdst, voffset, saddr.
-        asm volatile("" : "+v"(gl), "+v"(env));
-        // =============== Modular2D.step: controllers, PID -> motorSpeed ===============
-        {
-            float angParent = __shfl(ang, pl);
-            if (hasJoint) {
-                double ist = LD(D_CISTATE) + LD(D_CFREQ);
-                LD(D_CISTATE) = ist;
-                double target = (LD(D_CAMP) * dev_sin(ist + LD(D_CPHASE))) + LD(D_COFFSET);
-                float jointAngle = ang - angParent - 0.0f;
-                double speed = (target - (double)jointAngle) * 1.9;
-                motorSpeed = (float)speed;
-            }
-            if (active && jointed) { // b2RevoluteJoint::SetMotorSpeed -> SetAwake(true) on both bodies
-                if (sleepResetAlways || !awake) sleepT = 0.0f;
-                awake = 1;
-            }
-        }
-        // =============== b2World::Step ===============
-        const float c0x = px, c0y = py, a0 = ang; // sweep start (b2Island::Solve: c0 = c, a0 = a)
-        const float dtRatio = invDt0 * h;
-        const float hx = LF(L_HX), hy = LF(L_HY);
-        const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
-        V2 fatLo = mk(LF(L_FATLX), LF(L_FATLY)), fatHi = mk(LF(L_FATUX), LF(L_FATUY));
-        if (newFix) { // FindNewContacts for freshly created fixtures
-            if (active && find_new_pairs(S, T, gl, cCount, fatLo, fatHi, err)) {
-                if (sleepResetAlways || !awake) sleepT = 0.0f;
-                awake = 1;
-            }
-            newFix = 0;
-        }
-        Rot q = rot_set(ang); // body transform m_xf (q from sweep.a, p = c since localCenter = 0)
-        // ---- b2ContactManager::Collide: destroy separated pairs, update manifolds ----
-        int nTouch = 0;
-        unsigned slotPack = 0u;
-        if (active && awake) {
-            int s = 0;
-            while (s < cCount) {
-                unsigned o = (unsigned)s * Lp + gl;
-                int e = CI(C_EDGE, o);
-                if (!aabb_overlap(mk(T.flx[e], T.fly[e]), mk(T.fux[e], T.fuy[e]), fatLo, fatHi)) {
-                    // b2ContactManager::Destroy wakes the bodies of a touching contact
-                    if ((CI(C_INFO, o) & 0xff) > 0 && sleepResetAlways) sleepT = 0.0f;
-                    pairs_remove(S, gl, cCount, s);
-                    continue;
-                }
-                Manifold m;
-                contact_update_slot(S, T, o, shape, hx, hy, mk(px, py), q, m, sleepResetAlways, sleepT);
-                if (m.count > 0) {
-                    if (nTouch < KT) {
-                        manifold_store(S, gl, nTouch, m);
-                        slotPack |= (unsigned)s << (5 * nTouch);
-                        ++nTouch;
-                    } else {
-                        err |= REM2D_ERR_SOLVER_OVERFLOW;
-                    }
-                }
-                ++s;
-            }
-        }
-        // =============== b2World::Solve ===============
-        // the creature is one island; it is simulated iff any of its bodies is awake
-        const int envAwake = group_or<K>(active && awake ? 1 : 0);
-        if (envAwake) {
-            if (active && (!awake || sleepResetAlways)) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
-            // ---- integrate velocities (gravity (0,-10), no forces, no damping) ----
-            if (active) {
-                V2 acc = vadd(vscale(1.0f, mk(0.0f, -10.0f)), vscale(mB, mk(0.0f, 0.0f)));
-                V2 v = vadd(mk(vx, vy), vscale(h, acc));
-                float wz = w + h * iB * 0.0f;
-                v = vscale(1.0f / (1.0f + h * 0.0f), v);
-                wz *= 1.0f / (1.0f + h * 0.0f);
-                vx = v.x; vy = v.y; w = wz;
-            }
-            // ---- contact constraints: b2ContactSolver ctor + InitializeVelocityConstraints + WarmStart ----
-            ContactC cc[KR];
-            const bool anyOverflow = __any(nTouch > KR ? 1 : 0);
-#pragma unroll
-            for (int t = 0; t < KR; ++t) {
-                cc[t].count = 0;
-                if (t < nTouch) {
-                    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
-                    int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
-                    contact_setup(cc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
-                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
-                                  dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
-                    contact_warm_start(cc[t], mB, iB, vx, vy, w);
-                }
-            }
-            if (anyOverflow) {
-                for (int t = KR; t < nTouch; ++t) {
-                    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
-                    int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
-                    ContactC c;
-                    contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
-                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
-                                  dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
-                    contact_warm_start(c, mB, iB, vx, vy, w);
-                    cc_store(S, (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl, c);
-                }
-            }
-            // ---- joints: InitVelocityConstraints (warm start), in island rounds ----
-            V2 rA = mk(0.0f, 0.0f), rB = mk(0.0f, 0.0f);
-            float m_exx = 0.0f, m_eyx = 0.0f, m_ezx = 0.0f, m_eyy = 0.0f, m_ezy = 0.0f, m_ezz = 0.0f, motorMass = 0.0f;
-            float det33 = 0.0f, det22 = 0.0f, cyz_x = 0.0f, cyz_y = 0.0f, cyz_z = 0.0f;
-            float maxMotorImpulse = 0.0f;
-            {
-                float sA = __shfl(q.s, pl), cA = __shfl(q.c, pl);
-                float aA = __shfl(ang, pl);
-                if (hasJoint) {
-                    const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
-                    const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
-                    maxMotorImpulse = h * LF(L_JTORQUE);
-                    Rot qA; qA.s = sA; qA.c = cA;
-                    rA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
-                    rB = rmul(q, vsub(anchorB, mk(0.0f, 0.0f)));
-                    m_exx = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
-                    m_eyx = -rA.y * rA.x * iA - rB.y * rB.x * iB;
-                    m_ezx = -rA.y * iA - rB.y * iB;
-                    m_eyy = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
-                    m_ezy = rA.x * iA + rB.x * iB;
-                    m_ezz = iA + iB;
-                    motorMass = iA + iB;
-                    if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
-                    float jointAngle = ang - aA - 0.0f;
-                    if (fabs32(jUpper - jLower) < 2.0f * B2_ANGULAR_SLOP) {
-                        limitState = LIM_EQUAL;
-                    } else if (jointAngle <= jLower) {
-                        if (limitState != LIM_AT_LOWER) impZ = 0.0f;
-                        limitState = LIM_AT_LOWER;
-                    } else if (jointAngle >= jUpper) {
-                        if (limitState != LIM_AT_UPPER) impZ = 0.0f;
-                        limitState = LIM_AT_UPPER;
-                    } else {
-                        limitState = LIM_INACTIVE;
-                        impZ = 0.0f;
-                    }
-                    impX *= dtRatio; impY *= dtRatio; impZ *= dtRatio; motorImp *= dtRatio;
-                    // loop invariants of b2Mat33::Solve33 / Solve22 (same expressions, evaluated once)
-                    // ex = (m_exx, m_eyx, m_ezx), ey = (m_eyx, m_eyy, m_ezy), ez = (m_ezx, m_ezy, m_ezz)
-                    cyz_x = m_eyy * m_ezz - m_ezy * m_ezy;
-                    cyz_y = m_ezy * m_ezx - m_eyx * m_ezz;
-                    cyz_z = m_eyx * m_ezy - m_eyy * m_ezx;
-                    det33 = m_exx * cyz_x + m_eyx * cyz_y + m_ezx * cyz_z;
-                    if (det33 != 0.0f) det33 = 1.0f / det33;
-                    det22 = m_exx * m_eyy - m_eyx * m_eyx;
-                    if (det22 != 0.0f) det22 = 1.0f / det22;
-                }
-            }
-            if (nRounds > 0) {
-                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
-                lds_sync();
-                for (int r = 0; r < nRounds; ++r) {
-                    if (jround == r) {
-                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
-                        float wA = mbox[2][pl];
-                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
-                        float wB = mbox[2][lane];
-                        V2 P = mk(impX, impY);
-                        vA = vsub(vA, vscale(mA, P));
-                        wA -= iA * (vcross(rA, P) + motorImp + impZ);
-                        vB = vadd(vB, vscale(mB, P));
-                        wB += iB * (vcross(rB, P) + motorImp + impZ);
-                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
-                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
-                    }
-                    lds_sync();
-                }
-                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
-            }
-            // ---- velocity iterations, software-pipelined across iterations ----
-            // One tick = a joint slot then a contact slot.  Joint (parent, this body) of iteration t fires
-            // at tick jround + t*period, this body's contacts at offC + t*period; the host proves that any
-            // two operations sharing a body keep Box2D's sequential order, so the result is bit-identical
-            // to "for it: all joints in island order; all contacts" while a chain of J joints costs
-            // `period` (2..4) slots per iteration instead of J.  Velocities live in the LDS mailbox.
-            {
-                const int iters = A.velIters;
-                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
-                lds_sync();
-                int nextJ = (hasJoint && iters > 0) ? jround : 0x7fffffff, leftJ = iters;
-                int nextC = (active && nTouch > 0 && iters > 0) ? offC : 0x7fffffff, leftC = iters;
-                const int nTicks = wave_max((active && iters > 0) ? offC + (iters - 1) * period : -1) + 1;
-                for (int tick = 0; tick < nTicks; ++tick) {
-                    if (tick == nextJ) {
-                        nextJ = (--leftJ > 0) ? nextJ + period : 0x7fffffff;
-                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
-                        float wA = mbox[2][pl];
-                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
-                        float wB = mbox[2][lane];
-                        // motor
-                        if (limitState != LIM_EQUAL) {
-                            float Cdot = wB - wA - motorSpeed;
-                            float impulse = -motorMass * Cdot;
-                            float oldImpulse = motorImp;
-                            motorImp = fclamp(oldImpulse + impulse, -maxMotorImpulse, maxMotorImpulse);
-                            impulse = motorImp - oldImpulse;
-                            wA -= iA * impulse;
-                            wB += iB * impulse;
-                        }
-                        if (limitState != LIM_INACTIVE) {
-                            V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
-                            float Cdot2 = wB - wA;
-                            // impulse = -m_mass.Solve33(Cdot)
-                            float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
-                            float sx = det33 * (bx * cyz_x + by * cyz_y + bz * cyz_z);
-                            float cbx = by * m_ezz - bz * m_ezy, cby = bz * m_ezx - bx * m_ezz, cbz = bx * m_ezy - by * m_ezx;
-                            float sy = det33 * (m_exx * cbx + m_eyx * cby + m_ezx * cbz);
-                            float ebx = m_eyy * bz - m_ezy * by, eby = m_ezy * bx - m_eyx * bz, ebz = m_eyx * by - m_eyy * bx;
-                            float sz = det33 * (m_exx * ebx + m_eyx * eby + m_ezx * ebz);
-                            float ix = -sx, iy = -sy, iz = -sz;
-                            if (limitState == LIM_EQUAL) {
-                                impX += ix; impY += iy; impZ += iz;
-                            } else {
-                                float newImpulse = impZ + iz;
-                                bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
-                                if (reduce) {
-                                    V2 rhs = vadd(vneg(Cdot1), vscale(impZ, mk(m_ezx, m_ezy)));
-                                    float rx = det22 * (m_eyy * rhs.x - m_eyx * rhs.y);
-                                    float ry = det22 * (m_exx * rhs.y - m_eyx * rhs.x);
-                                    ix = rx; iy = ry; iz = -impZ;
-                                    impX += rx; impY += ry; impZ = 0.0f;
-                                } else {
-                                    impX += ix; impY += iy; impZ += iz;
-                                }
-                            }
-                            V2 P = mk(ix, iy);
-                            vA = vsub(vA, vscale(mA, P));
-                            wA -= iA * (vcross(rA, P) + iz);
-                            vB = vadd(vB, vscale(mB, P));
-                            wB += iB * (vcross(rB, P) + iz);
-                        } else {
-                            V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, rB)), vA), vcross_sv(wA, rA));
-                            V2 b = vneg(Cdot);
-                            V2 impulse = mk(det22 * (m_eyy * b.x - m_eyx * b.y), det22 * (m_exx * b.y - m_eyx * b.x));
-                            impX += impulse.x; impY += impulse.y;
-                            vA = vsub(vA, vscale(mA, impulse));
-                            wA -= iA * vcross(rA, impulse);
-                            vB = vadd(vB, vscale(mB, impulse));
-                            wB += iB * vcross(rB, impulse);
-                        }
-                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
-                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
-                    }
-                    lds_sync();
-                    if (tick == nextC) { // contacts of this body, in list order
-                        nextC = (--leftC > 0) ? nextC + period : 0x7fffffff;
-                        float cvx = mbox[0][lane], cvy = mbox[1][lane], cw = mbox[2][lane];
-#pragma unroll
-                        for (int t = 0; t < KR; ++t)
-                            if (t < nTouch) contact_solve(cc[t], mB, iB, friction, cvx, cvy, cw);
-                        if (nTouch > KR) {
-                            for (int t = KR; t < nTouch; ++t) {
-                                const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
-                                ContactC c;
-                                cc_load(S, cb, c);
-                                contact_solve(c, mB, iB, friction, cvx, cvy, cw);
-                                SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
-                            }
-                        }
-                        mbox[0][lane] = cvx; mbox[1][lane] = cvy; mbox[2][lane] = cw;
-                    }
-                    lds_sync();
-                }
-                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
-            }
-            // ---- StoreImpulses ----
-#pragma unroll
-            for (int t = 0; t < KR; ++t) {
-                if (t < nTouch) {
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
-                    CF(C_N0, o) = cc[t].n0;
-                    CF(C_T0, o) = cc[t].t0;
-                    if (cc[t].count > 1) {
-                        CF(C_N1, o) = cc[t].n1;
-                        CF(C_T1, o) = cc[t].t1;
-                    }
-                }
-            }
-            if (anyOverflow) {
-                for (int t = KR; t < nTouch; ++t) {
-                    const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
-                    CF(C_N0, o) = SW(cb, 10);
-                    CF(C_T0, o) = SW(cb, 12);
-                    if (__float_as_int(SW(cb, 20)) > 1) {
-                        CF(C_N1, o) = SW(cb, 11);
-                        CF(C_T1, o) = SW(cb, 13);
-                    }
-                }
-            }
-            // ---- integrate positions ----
-            if (active) {
-                V2 v = mk(vx, vy);
-                V2 translation = vscale(h, v);
-                if (vdot(translation, translation) > B2_MAX_TRANSLATION_SQ) {
-                    float ratio = B2_MAX_TRANSLATION / vlen(translation);
-                    v = vscale(ratio, v);
-                }
-                float rotation = h * w;
-                if (rotation * rotation > B2_MAX_ROTATION_SQ) {
-                    float ratio = B2_MAX_ROTATION / fabs32(rotation);
-                    w *= ratio;
-                }
-                px = px + h * v.x;
-                py = py + h * v.y;
-                ang += h * w;
-                vx = v.x; vy = v.y;
-            }
-            // ---- position iterations (per creature early exit) ----
-            bool envSolved = false;
-            int itersUsed = A.posIters;
-            {
-                const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
-                const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
-                for (int it = 0; it < A.posIters; ++it) {
-                    float minSeparation = 0.0f;
-                    if (!envSolved && active) {
-                        for (int t = 0; t < nTouch; ++t) {
-                            const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
-                            int tc = __float_as_int(SW(sb, 0));
-                            int mtype = tc & 0xff, mcount = tc >> 8;
-                            V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
-                            const float radiusA = B2_POLYGON_RADIUS;
-                            for (int j = 0; j < mcount; ++j) {
-                                V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
-                                V2 cB = mk(px, py);
-                                V2 normal, point;
-                                float separation;
-                                Rot qB = rot_set(ang);
-                                if (mtype == MF_CIRCLES) {
-                                    V2 pointA = lp;
-                                    V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
-                                    normal = vsub(pointB, pointA);
-                                    vnormalize(normal);
-                                    point = vscale(0.5f, vadd(pointA, pointB));
-                                    separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                                } else if (mtype == MF_FACE_A) {
-                                    normal = ln;
-                                    V2 planePoint = lp;
-                                    V2 clipPoint = xmul(qB, cB, pj);
-                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                    point = clipPoint;
-                                } else {
-                                    normal = rmul(qB, ln);
-                                    V2 planePoint = xmul(qB, cB, lp);
-                                    V2 clipPoint = pj;
-                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                    point = clipPoint;
-                                    normal = vneg(normal);
-                                }
-                                V2 rBp = vsub(point, cB);
-                                minSeparation = fmin32(minSeparation, separation);
-                                float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                                float rnB = vcross(rBp, normal);
-                                float Kn = mB + iB * rnB * rnB;
-                                float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                                V2 P = vscale(impulse, normal);
-                                px = px + mB * P.x;
-                                py = py + mB * P.y;
-                                ang += iB * vcross(rBp, P);
-                            }
-                        }
-                    }
-                    int jointOk = 1;
-                    if (nRounds > 0) {
-                        mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
-                        lds_sync();
-                        for (int r = 0; r < nRounds; ++r) {
-                            if (jround == r && !envSolved) {
-                                V2 cA = mk(mbox[0][pl], mbox[1][pl]);
-                                float aA = mbox[2][pl];
-                                V2 cB = mk(mbox[0][lane], mbox[1][lane]);
-                                float aB = mbox[2][lane];
-                                float angularError = 0.0f, positionError = 0.0f;
-                                if (limitState != LIM_INACTIVE) {
-                                    float angle = aB - aA - 0.0f;
-                                    float limitImpulse = 0.0f;
-                                    if (limitState == LIM_EQUAL) {
-                                        float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
-                                        limitImpulse = -motorMass * C;
-                                        angularError = fabs32(C);
-                                    } else if (limitState == LIM_AT_LOWER) {
-                                        float C = angle - jLower;
-                                        angularError = -C;
-                                        C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
-                                        limitImpulse = -motorMass * C;
-                                    } else {
-                                        float C = angle - jUpper;
-                                        angularError = C;
-                                        C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
-                                        limitImpulse = -motorMass * C;
-                                    }
-                                    aA -= iA * limitImpulse;
-                                    aB += iB * limitImpulse;
-                                }
-                                {
-                                    Rot qA = rot_set(aA), qB = rot_set(aB);
-                                    V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
-                                    V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
-                                    V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
-                                    positionError = vlen(C);
-                                    float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
-                                    float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
-                                    float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
-                                    float det = Kexx * Keyy - Kexy * Kexy;
-                                    if (det != 0.0f) det = 1.0f / det;
-                                    V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
-                                    V2 impulse = vneg(sol);
-                                    cA = vsub(cA, vscale(mA, impulse));
-                                    aA -= iA * vcross(prA, impulse);
-                                    cB = vadd(cB, vscale(mB, impulse));
-                                    aB += iB * vcross(prB, impulse);
-                                }
-                                mbox[0][pl] = cA.x; mbox[1][pl] = cA.y; mbox[2][pl] = aA;
-                                mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
-                                jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
-                            }
-                            lds_sync();
-                        }
-                        px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
-                    }
-                    float envMinSep = group_min<K>(minSeparation);
-                    int envJointsOk = group_and<K>(jointOk);
-                    bool okNow = (envMinSep >= -3.0f * B2_LINEAR_SLOP) && envJointsOk;
-                    if (!envSolved && okNow) { envSolved = true; itersUsed = it + 1; }
-                    if (__all(envSolved ? 1 : 0)) break;
-                }
-            }
-            lastPosIters = itersUsed;
-            // ---- sleep ----
-            if (allowSleep) {
-                float myT = FLT_MAX;
-                if (active) {
-                    const float linTolSqr = B2_LINEAR_SLEEP_TOL * B2_LINEAR_SLEEP_TOL;
-                    const float angTolSqr = B2_ANGULAR_SLEEP_TOL * B2_ANGULAR_SLEEP_TOL;
-                    if (w * w > angTolSqr || vdot(mk(vx, vy), mk(vx, vy)) > linTolSqr) {
-                        sleepT = 0.0f;
-                        myT = 0.0f;
-                    } else {
-                        sleepT += h;
-                        myT = sleepT;
-                    }
-                }
-                float minSleepTime = group_min<K>(myT);
-                if (minSleepTime >= B2_TIME_TO_SLEEP && envSolved && active) {
-                    awake = 0; sleepT = 0.0f; vx = 0.0f; vy = 0.0f; w = 0.0f;
-                }
-            }
-            // ---- SynchronizeFixtures: swept AABB vs fat AABB (b2DynamicTree::MoveProxy) ----
-            if (active) {
-                Rot q0 = rot_set(a0);
-                Rot q1 = rot_set(ang);
-                V2 p0 = vsub(mk(c0x, c0y), rmul(q0, mk(0.0f, 0.0f)));
-                V2 p1 = vsub(mk(px, py), rmul(q1, mk(0.0f, 0.0f)));
-                AABB b1 = body_aabb(shape, hx, hy, p0, q0), b2 = body_aabb(shape, hx, hy, p1, q1);
-                V2 lo = vmin2(b1.lo, b2.lo), hi = vmax2(b1.hi, b2.hi);
-                V2 displacement = vsub(p1, p0);
-                bool contains = fatLo.x <= lo.x && fatLo.y <= lo.y && hi.x <= fatHi.x && hi.y <= fatHi.y;
-                if (!contains) {
-                    V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
-                    V2 flo = vsub(lo, r), fhi = vadd(hi, r);
-                    V2 d = vscale(B2_AABB_MULTIPLIER, displacement);
-                    if (d.x < 0.0f) flo.x += d.x; else fhi.x += d.x;
-                    if (d.y < 0.0f) flo.y += d.y; else fhi.y += d.y;
-                    LF(L_FATLX) = flo.x; LF(L_FATLY) = flo.y; LF(L_FATUX) = fhi.x; LF(L_FATUY) = fhi.y;
-                    if (find_new_pairs(S, T, gl, cCount, flo, fhi, err)) {
-                        if (sleepResetAlways || !awake) sleepT = 0.0f; // AddPair -> SetAwake(true)
-                        awake = 1;
-                    }
-                }
-            }
-        }
-        if (A.defer) { // continuous physics: the TOI kernel needs the sweep start and finishes the step
-            const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
-            SW(wb, 0) = c0x; SW(wb, 1) = c0y; SW(wb, 2) = a0;
-        }
-        if (h > 0.0f) invDt0 = inv_dt;
-        if (!A.defer) env_bookkeeping(S, env, sub, __shfl(px, base));
-    }
-    // ---- store ----
-    gl = gl0; env = env0;
-    LF(L_PX) = px; LF(L_PY) = py; LF(L_ANG) = ang; LF(L_VX) = vx; LF(L_VY) = vy; LF(L_W) = w;
-    LF(L_SLEEPT) = sleepT; LI(L_AWAKE) = awake;
-    LI(L_CCOUNT) = cCount;
-    LF(L_JIMPX) = impX; LF(L_JIMPY) = impY; LF(L_JIMPZ) = impZ; LF(L_JMOTORIMP) = motorImp;
-    LI(L_JLIMIT) = limitState; LF(L_JMOTORSPEED) = motorSpeed;
-    int envErr = group_or<K>(err);
-    if (sub == 0) {
-        EF(E_INVDT0) = invDt0;
-        EI(E_NEWFIX) = newFix; EI(E_ERR) = EI(E_ERR) | envErr; EI(E_POSITERS) = lastPosIters;
-    }
-}
-
-// =====================================================================================
-// TOI kernel: b2World::SolveTOI for every lane, then the per-step bookkeeping.  Launched after
-// rem2d_step_kernel (nSteps = 1, defer = 1) when REM2D_FLAG_CONTINUOUS is set; kept out of the
-// step kernel so that its branchy GJK / root-finder code does not share a register allocation
-// with the velocity loop.
-// =====================================================================================
-template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_kernel(State S, Terrain T, StepArgs A) {
-    const int lane = threadIdx.x;
-    const unsigned gl = blockIdx.x * WAVE + lane;
-    const unsigned env = gl / K;
-    const int base = lane & ~(K - 1);
-    const int sub = lane & (K - 1);
-    const int shape = LI(L_SHAPE);
-    float px = LF(L_PX);
-    if (shape != SHAPE_NONE && A.dt > 0.0f) {
-        const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
-        LaneBody B;
-        B.px = px; B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
-        B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
-        B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
-                           SW(wb, 2), B);
-        LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
-        LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
-        if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
-        if (B.err) atomicOr(&EI(E_ERR), B.err);
-        px = B.px;
-    }
-    env_bookkeeping(S, env, sub, __shfl(px, base));
-}
-
-// =====================================================================================
-// reset kernel: Modular2D.reset -> b2World() + create_robot
-// =====================================================================================
-DEV void box_mass(float hx, float hy, float &mass, float &I) { // b2PolygonShape::ComputeMass, density 1
-    const V2 vs[4] = {mk(-hx, -hy), mk(hx, -hy), mk(hx, hy), mk(-hx, hy)};
-    V2 center = mk(0.0f, 0.0f);
-    float area = 0.0f, In = 0.0f;
-    V2 s = mk(0.0f, 0.0f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s = vadd(s, vs[i]);
-    s = vscale(1.0f / 4.0f, s);
-    const float k_inv3 = 1.0f / 3.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        V2 e1 = vsub(vs[i], s);
-        V2 e2 = vsub(vs[(i + 1) & 3], s);
-        float D = vcross(e1, e2);
-        float triangleArea = 0.5f * D;
-        area += triangleArea;
-        center = vadd(center, vscale(triangleArea * k_inv3, vadd(e1, e2)));
-        float ex1 = e1.x, ey1 = e1.y, ex2 = e2.x, ey2 = e2.y;
-        float intx2 = ex1 * ex1 + ex2 * ex1 + ex2 * ex2;
-        float inty2 = ey1 * ey1 + ey2 * ey1 + ey2 * ey2;
-        In += (0.25f * k_inv3 * D) * (intx2 + inty2);
-    }
-    const float density = 1.0f;
-    mass = density * area;
-    center = vscale(1.0f / area, center);
-    V2 mc = vadd(center, s);
-    float Iout = density * In;
-    Iout += mass * (vdot(mc, mc) - vdot(center, center));
-    // b2Body::ResetMassData with a single fixture
-    float m = 0.0f + mass;
-    V2 lc = vadd(mk(0.0f, 0.0f), vscale(mass, mc));
-    float Ib = 0.0f + Iout;
-    float invM = 1.0f / m;
-    lc = vscale(invM, lc);
-    Ib -= m * vdot(lc, lc);
-    mass = m;
-    I = Ib;
-}
-__global__ void rem2d_reset_kernel(State S, rem2d_morph M, int K) {
-    unsigned gl = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gl >= S.Lp) return;
-    unsigned env = gl / (unsigned)K, sub = gl % (unsigned)K;
-    bool real = env < S.nEnvs;
-    int shape = real ? M.shape[gl] : 0;
-    float hx = real ? M.hx[gl] : 0.0f, hy = real ? M.hy[gl] : 0.0f;
-    float x = real ? M.x[gl] : 0.0f, y = real ? M.y[gl] : 0.0f, a = real ? M.angle[gl] : 0.0f;
-    float invM = 0.0f, invI = 0.0f;
-    if (shape == SHAPE_BOX) {
-        float m, I;
-        box_mass(hx, hy, m, I);
-        invM = 1.0f / m;
-        invI = I > 0.0f ? 1.0f / I : 0.0f;
-    } else if (shape == SHAPE_CIRCLE) {
-        const float density = 1.0f;
-        float mass = density * B2_PI * hx * hx;
-        float I = mass * (0.5f * hx * hx + vdot(mk(0.0f, 0.0f), mk(0.0f, 0.0f)));
-        float m = 0.0f + mass;
-        V2 lc = vadd(mk(0.0f, 0.0f), vscale(mass, mk(0.0f, 0.0f)));
-        float Ib = 0.0f + I;
-        invM = 1.0f / m;
-        lc = vscale(invM, lc);
-        Ib -= m * vdot(lc, lc);
-        invI = Ib > 0.0f ? 1.0f / Ib : 0.0f;
-    }
-    LI(L_SHAPE) = shape;
-    LF(L_HX) = hx; LF(L_HY) = hy; LF(L_INVM) = invM; LF(L_INVI) = invI;
-    // b2Body ctor + ResetMassData: sweep.c = b2Mul(xf, localCenter = 0)
-    Rot q = rot_set(a);
-    V2 c = xmul(q, mk(x, y), mk(0.0f, 0.0f));
-    LF(L_PX) = c.x; LF(L_PY) = c.y; LF(L_ANG) = a;
-    LF(L_VX) = 0.0f; LF(L_VY) = 0.0f; LF(L_W) = 0.0f; LF(L_SLEEPT) = 0.0f;
-    LI(L_AWAKE) = shape != SHAPE_NONE ? 1 : 0;
-    // b2Fixture::CreateProxies: fat AABB of the initial transform
-    AABB bb = body_aabb(shape == SHAPE_NONE ? SHAPE_CIRCLE : shape, hx, hy, mk(x, y), q);
-    V2 r = mk(B2_AABB_EXTENSION, B2_AABB_EXTENSION);
-    V2 lo = vsub(bb.lo, r), hi = vadd(bb.hi, r);
-    LF(L_FATLX) = lo.x; LF(L_FATLY) = lo.y; LF(L_FATUX) = hi.x; LF(L_FATUY) = hi.y;
-    int parent = real && shape != SHAPE_NONE ? M.parent[gl] : -1;
-    LI(L_PARENT) = parent;
-    LI(L_JROUND) = real ? M.jround[gl] : 0;
-    LF(L_JAX) = real ? M.ax[gl] : 0.0f; LF(L_JAY) = real ? M.ay[gl] : 0.0f;
-    LF(L_JBX) = real ? M.bx[gl] : 0.0f; LF(L_JBY) = real ? M.by[gl] : 0.0f;
-    LF(L_JTORQUE) = real ? M.torque[gl] : 0.0f; LF(L_JLOWER) = real ? M.lower[gl] : 0.0f;
-    LF(L_JUPPER) = real ? M.upper[gl] : 0.0f;
-    LF(L_JIMPX) = 0.0f; LF(L_JIMPY) = 0.0f; LF(L_JIMPZ) = 0.0f; LF(L_JMOTORIMP) = 0.0f; LF(L_JMOTORSPEED) = 0.0f;
-    LI(L_JLIMIT) = LIM_INACTIVE;
-    LD(D_CAMP) = real ? M.amp[gl] : 0.0; LD(D_CPHASE) = real ? M.phase[gl] : 0.0; LD(D_CFREQ) = real ? M.freq[gl] : 0.0;
-    LD(D_COFFSET) = real ? M.offset[gl] : 0.0; LD(D_CISTATE) = real ? M.istate[gl] : 0.0;
-    LI(L_CCOUNT) = 0;
-    for (int s = 0; s < KC; ++s) {
-        unsigned o = (unsigned)s * S.Lp + gl;
-        CI(C_EDGE, o) = -1; CI(C_INFO, o) = 0; CU(C_KEY0, o) = 0u; CU(C_KEY1, o) = 0u;
-        CF(C_N0, o) = 0.0f; CF(C_N1, o) = 0.0f; CF(C_T0, o) = 0.0f; CF(C_T1, o) = 0.0f;
-    }
-    if (sub == 0) {
-        ED(E_WOD) = 0.0; ED(E_FITNESS) = 0.0; EF(E_REWARD) = 0.0f; EI(E_DONE) = 0; EI(E_EVERDONE) = 0;
-        EI(E_FROZEN) = 0; EI(E_STEPS) = 0; EF(E_INVDT0) = 0.0f; EI(E_NEWFIX) = 1; EI(E_ERR) = 0;
-        EI(E_POSITERS) = 0; EI(E_TOIEVENTS) = 0;
-    }
-}
+#include "rem2d_state.h"
+#include "rem2d_math.h"
+#include "rem2d_narrowphase.h"
+#include "rem2d_solver.h"
+#include "rem2d_toi.h"
+#include "rem2d_kernels.h"
 
 // =====================================================================================
 // host side: handle + C ABI
