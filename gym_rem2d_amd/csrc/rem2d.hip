@@ -19,7 +19,7 @@
 //   * the per-body broadphase pair list (edge index, feature keys, warm-start impulses) is
 //     SoA in HBM ([slot][lane], coalesced) and walked with rolled loops.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (every binary32 operation rounded
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (every binary32 operation rounded
 // separately, like an x86-64 Box2D build; this is what makes bit-exact parity possible).
 #include <hip/hip_runtime.h>
 
