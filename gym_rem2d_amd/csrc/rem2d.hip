@@ -341,14 +341,21 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
             HIP_TRY(hipEventCreate(&e1));
             HIP_TRY(hipEventRecord(e0, st));
         }
+        // 3 waves/SIMD only when the grid can fill them (> 2 waves per SIMD on 256 CUs x 4 SIMDs)
+        static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
+        const bool three = forced ? forced == 3 : grid.x > 2u * 1024u * 2u;
+#define LAUNCH_STEP(KK)                                                                              \
+    if (three) hipLaunchKernelGGL((rem2d_step_kernel<KK, 3>), grid, block, 0, st, w->S, w->T, A);  \
+    else hipLaunchKernelGGL((rem2d_step_kernel<KK, 2>), grid, block, 0, st, w->S, w->T, A)
         switch (w->cfg.lanes) {
-        case 2: hipLaunchKernelGGL(rem2d_step_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
-        case 4: hipLaunchKernelGGL(rem2d_step_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
-        case 8: hipLaunchKernelGGL(rem2d_step_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
-        case 16: hipLaunchKernelGGL(rem2d_step_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
-        case 32: hipLaunchKernelGGL(rem2d_step_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
-        default: hipLaunchKernelGGL(rem2d_step_kernel<64>, grid, block, 0, st, w->S, w->T, A); break;
+        case 2: LAUNCH_STEP(2); break;
+        case 4: LAUNCH_STEP(4); break;
+        case 8: LAUNCH_STEP(8); break;
+        case 16: LAUNCH_STEP(16); break;
+        case 32: LAUNCH_STEP(32); break;
+        default: LAUNCH_STEP(64); break;
         }
+#undef LAUNCH_STEP
         if (w->timing) {
             HIP_TRY(hipEventRecord(e1, st));
             w->pending.emplace_back(e0, e1);

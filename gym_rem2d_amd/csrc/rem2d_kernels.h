@@ -35,8 +35,10 @@ struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TO
 // joint effective-mass terms and impulses, KR contact constraints); everything else (pose
 // history, shape, fat AABB, anchors, controller, per-creature bookkeeping) is re-read from
 // HBM/L2 at its point of use once per step, so that the kernel fits two waves per SIMD.
-template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
+// W = waves per SIMD the register allocation targets: 2 (238 VGPRs, no spills) or 3 (168 VGPRs, ~95 spilled
+// outside the velocity loop); 3 pays off only when the launch has enough waves to fill the extra slots.
+template <int K, int W>
+__global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
     __shared__ float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
     const int lane = threadIdx.x;
     const unsigned gl0 = blockIdx.x * WAVE + lane;
