@@ -170,19 +170,31 @@ def pipeline_schedule(n_bodies, joints, rounds):
     """Modulo schedule of the velocity iterations (one tick = a joint slot, then a contact slot).
 
     Joint k of iteration t fires at tick ``rounds[k] + t*P``; body b's contacts of iteration t at
-    ``offC[b] + t*P`` with ``offC[b]`` = the last joint slot that touches b.  ``P`` is the smallest
+    ``offC[b] + t*P`` with ``offC[b]`` at or after the last joint slot that touches b.  ``P`` is the smallest
     period for which joint k of iteration t+1 starts strictly after the contact slots (iteration t)
     of both of its bodies.  Every pair of operations that share a body then runs in Box2D's
     sequential order (joints in island order, then contacts, iteration after iteration), so the
     pipelined sweep is bit-identical to the sequential one while the chain of joints no longer
     serialises a whole iteration."""
-    offC = [0] * n_bodies
+    last = [0] * n_bodies
+    first = [None] * n_bodies
     for k, (a, b) in enumerate(joints):
-        offC[a] = max(offC[a], rounds[k])
-        offC[b] = max(offC[b], rounds[k])
+        for x in (a, b):
+            last[x] = max(last[x], rounds[k])
+            first[x] = rounds[k] if first[x] is None else min(first[x], rounds[k])
     period = 1
     for k, (a, b) in enumerate(joints):
-        period = max(period, max(offC[a], offC[b]) + 1 - rounds[k])
+        period = max(period, max(last[a], last[b]) + 1 - rounds[k])
+    # Body b's contact slot may sit anywhere in [last[b], first[b] + period - 1] (after its last joint of
+    # this iteration, before its first joint of the next).  Where that window allows it, use the phase
+    # period-1 so that the contact slots of a whole wavefront coincide and the other ticks skip them.
+    offC = list(last)
+    for b in range(n_bodies):
+        if first[b] is None:
+            continue
+        v = last[b] + ((period - 1 - last[b]) % period)
+        if v <= first[b] + period - 1:
+            offC[b] = v
     return offC, period
 
 

@@ -157,3 +157,36 @@ def test_morphology_packing():
     assert np.array_equal(sub["x"][:32], m["x"][4 * 32:5 * 32]) and np.array_equal(sub["amp"][32:], m["amp"][32:64])
     rep = Morphology.replicate(specs[0], 5)
     assert rep.n_envs == 5 and np.array_equal(rep["hx"][:rep.lanes], rep["hx"][-rep.lanes:])
+
+
+def _check_pipeline(spec, iters=5):
+    """Replay the modulo schedule and compare, per body, the order of operations with Box2D's
+    sequential sweep: iteration by iteration, the body's joints in island order, then its contacts."""
+    pairs = [(j["parent"], j["child"]) for j in spec.joints]
+    P, n = spec.period, spec.n_bodies
+    pos = {k: i for i, k in enumerate(spec.island_order)}
+    events = []   # (tick, slot, body, label)
+    for t in range(iters):
+        for k, (a, b) in enumerate(pairs):
+            for x in (a, b):
+                events.append((spec.rounds[k] + t * P, 0, x, ("j", t, pos[k])))
+        for b in range(n):
+            events.append((spec.offC[b] + t * P, 1, b, ("c", t, 0)))
+    for b in range(n):
+        mine = sorted(e for e in events if e[2] == b)
+        # no two joints of one body in the same slot
+        slots = [(e[0], e[1]) for e in mine]
+        assert len(set(slots)) == len(slots)
+        got = [e[3] for e in mine]
+        want = sorted(got, key=lambda l: (l[1], 0 if l[0] == "j" else 1, l[2]))
+        assert got == want, (b, got[:8], want[:8])
+    assert max(spec.offC, default=0) < 256 and P < 256
+
+
+def test_pipeline_schedule_keeps_sequential_order():
+    from gym_rem2d_amd import synthetic
+    specs = synthetic.lsystem_specs(list(range(300))) + synthetic.direct_specs(list(range(100)))
+    specs += synthetic.cppn_specs(list(range(60)))
+    assert any(s.period >= 4 for s in specs)
+    for s in specs:
+        _check_pipeline(s)
