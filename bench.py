@@ -52,7 +52,12 @@ def pmc_traffic(kernel_name):
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d["kernels"][kernel_name]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        # profile keys carry both template arguments ("rem2d_step_kernel<16, 3>"); match on <K
+        stem = kernel_name.rstrip(">")
+        for k, v in d["kernels"].items():
+            if k == kernel_name or k.startswith(stem + ","):
+                return float(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        return None, None
     except Exception:  # noqa: BLE001
         return None, None
 

@@ -8,8 +8,10 @@ for API parity and for host-side tests.
 import math
 import random
 
+from .tree import FastCopy
 
-class Controller:
+
+class Controller(FastCopy):
     MAX_AMP = 1
     MAX_PHASE = 1
     MAX_OFFSET = math.pi

@@ -8,10 +8,10 @@ generator of BASELINE config 3 (65 536 random L-system creatures).
 import copy
 import random
 
-from ..tree import Node, Tree
+from ..tree import FastCopy, Node, Tree
 
 
-class Symbol:
+class Symbol(FastCopy):
     """Placeholder for one module occurrence while the string is rewritten."""
 
     def __init__(self, index, module, module_ref):
@@ -25,7 +25,7 @@ class Symbol:
         self.handled = False
 
 
-class Rule:
+class Rule(FastCopy):
     """A := A[children]; the left-hand symbol is kept and its products are attached to it."""
 
     def __init__(self, module_ref, module_list):

@@ -20,6 +20,7 @@ import random
 from enum import Enum
 
 from .controller import Controller
+from .tree import FastCopy
 
 
 class BoxConnection(Enum):
@@ -50,7 +51,7 @@ class ConnectionSite:
         self.orientation = orientation
 
 
-class Module:
+class Module(FastCopy):
     """Common tree helpers (abstract_module.py:23-53)."""
     connection_type = None
     _children = None

