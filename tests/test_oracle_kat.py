@@ -279,3 +279,25 @@ def test_static_box_terrain_contacts(oracle):
     assert 6.0 + 0.25 + 0.005 - 1e-3 <= b[1][1] <= 6.0 + 0.25 + 0.01 + 1e-3
     c1, _ = w.contacts(1)
     assert c1[c1[:, 0] == 0][0][1] == 1
+
+
+def test_oracle_matches_trajectory_digests(oracle):
+    """The committed digests (tests/golden/trajectory_digest.json, written by tools/make_trajectory_digest.py)
+    pin the oracle's trajectories across rounds, compilers and hosts: every operation is a separately rounded
+    IEEE binary32/binary64 operation and the trig is the documented rem2d polynomial, so they are portable."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_trajectory_digest as D
+    with open(os.path.join(root, "tests", "golden", "trajectory_digest.json")) as f:
+        gold = json.load(f)["cases"]
+    assert set(gold) == {c[0] for c in D.CASES}
+    for name, pop, ter, flags, steps in D.CASES:
+        m, t = D.population(pop), D.terrain(ter)
+        xs, ys, polys = t.f32()
+        ot = oracle.Terrain(xs, ys, polys if len(polys) else None, t.friction)
+        r = oracle.batch_run(ot, m.as_dict(), steps, n_threads=os.cpu_count() or 1, flags=flags)
+        assert (m.n_envs, m.lanes) == (gold[name]["n_envs"], gold[name]["lanes"])
+        assert D.digest(r["bodies"], m.n_bodies, r["reward"], r["done"], r["fitness"]) == gold[name]["sha256"], name

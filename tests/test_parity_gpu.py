@@ -278,3 +278,27 @@ def test_call_order_errors(gpu):
     with pytest.raises(ValueError):
         w.reset(synthetic.chain_population(3, 4))
     w.close()
+
+
+def test_gpu_matches_committed_trajectory_digests(gpu):
+    """Golden vectors without the oracle in the loop: the HIP path must reproduce the committed SHA-256
+    digests of poses, velocities, sleep timers, reward, done and fitness (tests/golden/trajectory_digest.json)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_trajectory_digest as D
+    with open(os.path.join(root, "tests", "golden", "trajectory_digest.json")) as f:
+        gold = json.load(f)["cases"]
+    for name, pop, ter, flags, steps in D.CASES:
+        m, t = D.population(pop), D.terrain(ter)
+        w = gpu(m.n_envs, m.lanes, flags)
+        w.set_terrain(t)
+        w.reset(m)
+        w.step(steps)
+        got = D.digest(w.bodies(), m.n_bodies, w.view("reward").cpu().numpy(), w.view("everdone").cpu().numpy(),
+                       w.view("fitness").cpu().numpy())
+        assert int(w.view("err").max()) == 0
+        w.close()
+        assert got == gold[name]["sha256"], name
