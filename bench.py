@@ -133,9 +133,13 @@ def main():
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1],
+                    help="0 = fused rem2d_step_kernel, 1 = split pre/vel/post pipeline (default: the library's default)")
     ap.add_argument("--discrete", action="store_true",
                     help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
     args = ap.parse_args()
+    if args.pipeline is not None:
+        os.environ["REM2D_PIPELINE"] = str(args.pipeline)  # read once by librem2d at the first step
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -70,6 +70,7 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_solver.h"
 #include "rem2d_toi.h"
 #include "rem2d_kernels.h"
+#include "rem2d_pipeline.h"
 
 // =====================================================================================
 // host side: handle + C ABI
@@ -324,53 +325,75 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
     const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
+    // REM2D_PIPELINE=0 selects the fused rem2d_step_kernel (one launch for all of Modular2D.step), the
+    // default is the split pipeline pre -> vel -> post whose velocity kernel maps lanes to constraints.
+    static const bool splitEnv = !(getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 0);
+    const bool split = splitEnv && pos_iters <= 64; // the pipelined position solver tracks iterations in a 64-bit mask
     StepArgs A;
-    A.nSteps = continuous ? 1 : n_steps;
+    A.nSteps = (continuous || split) ? 1 : n_steps;
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
     A.defer = continuous ? 1 : 0;
     dim3 grid((unsigned)w->L.Lp / WAVE), block(WAVE);
     hipStream_t st = (hipStream_t)stream;
-    const int launches = continuous ? n_steps : 1;
+    const int launches = (continuous || split) ? n_steps : 1;
     for (int l = 0; l < launches; ++l) {
-        // timing brackets the step kernel only (the dominant kernel; bench.py's roofline leg)
+        // timing brackets the dominant kernel only (bench.py's roofline leg): the fused step kernel, or the
+        // velocity kernel of the split pipeline
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (w->timing) {
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, st));
         }
-        // 3 waves/SIMD only when the grid can fill them (> 2 waves per SIMD on 256 CUs x 4 SIMDs)
-        static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
-        const bool three = forced ? forced == 3 : grid.x > 2u * 1024u * 2u;
+        if (split) {
+#define LAUNCH_K(NAME, KK) hipLaunchKernelGGL((NAME<KK>), grid, block, 0, st, w->S, w->T, A)
+#define LAUNCH_BY_LANES(NAME)                  \
+    switch (w->cfg.lanes) {                    \
+    case 2: LAUNCH_K(NAME, 2); break;          \
+    case 4: LAUNCH_K(NAME, 4); break;          \
+    case 8: LAUNCH_K(NAME, 8); break;          \
+    case 16: LAUNCH_K(NAME, 16); break;        \
+    case 32: LAUNCH_K(NAME, 32); break;        \
+    default: LAUNCH_K(NAME, 64); break;        \
+    }
+            LAUNCH_BY_LANES(rem2d_pre_kernel);
+            VelArgs V;
+            V.K = w->cfg.lanes;
+            V.velIters = vel_iters;
+            V.dt = dt;
+            V.friction = w->T.friction;
+            if (w->timing) HIP_TRY(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(rem2d_vel_kernel, dim3(((unsigned)w->L.Lp + VEL_THREADS - 1) / VEL_THREADS), dim3(VEL_THREADS), 0,
+                               st, w->S, V);
+            if (w->timing) HIP_TRY(hipEventRecord(e1, st));
+            LAUNCH_BY_LANES(rem2d_post_kernel);
+        } else {
+            if (w->timing) HIP_TRY(hipEventRecord(e0, st));
+            // 3 waves/SIMD only when the grid can fill them (> 2 waves per SIMD on 256 CUs x 4 SIMDs)
+            static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
+            const bool three = forced ? forced == 3 : grid.x > 2u * 1024u * 2u;
 #define LAUNCH_STEP(KK)                                                                              \
     if (three) hipLaunchKernelGGL((rem2d_step_kernel<KK, 3>), grid, block, 0, st, w->S, w->T, A);  \
     else hipLaunchKernelGGL((rem2d_step_kernel<KK, 2>), grid, block, 0, st, w->S, w->T, A)
-        switch (w->cfg.lanes) {
-        case 2: LAUNCH_STEP(2); break;
-        case 4: LAUNCH_STEP(4); break;
-        case 8: LAUNCH_STEP(8); break;
-        case 16: LAUNCH_STEP(16); break;
-        case 32: LAUNCH_STEP(32); break;
-        default: LAUNCH_STEP(64); break;
-        }
-#undef LAUNCH_STEP
-        if (w->timing) {
-            HIP_TRY(hipEventRecord(e1, st));
-            w->pending.emplace_back(e0, e1);
-        }
-        if (continuous) {
             switch (w->cfg.lanes) {
-            case 2: hipLaunchKernelGGL(rem2d_toi_kernel<2>, grid, block, 0, st, w->S, w->T, A); break;
-            case 4: hipLaunchKernelGGL(rem2d_toi_kernel<4>, grid, block, 0, st, w->S, w->T, A); break;
-            case 8: hipLaunchKernelGGL(rem2d_toi_kernel<8>, grid, block, 0, st, w->S, w->T, A); break;
-            case 16: hipLaunchKernelGGL(rem2d_toi_kernel<16>, grid, block, 0, st, w->S, w->T, A); break;
-            case 32: hipLaunchKernelGGL(rem2d_toi_kernel<32>, grid, block, 0, st, w->S, w->T, A); break;
-            default: hipLaunchKernelGGL(rem2d_toi_kernel<64>, grid, block, 0, st, w->S, w->T, A); break;
+            case 2: LAUNCH_STEP(2); break;
+            case 4: LAUNCH_STEP(4); break;
+            case 8: LAUNCH_STEP(8); break;
+            case 16: LAUNCH_STEP(16); break;
+            case 32: LAUNCH_STEP(32); break;
+            default: LAUNCH_STEP(64); break;
             }
+#undef LAUNCH_STEP
+            if (w->timing) HIP_TRY(hipEventRecord(e1, st));
+        }
+        if (w->timing) w->pending.emplace_back(e0, e1);
+        if (continuous) {
+            LAUNCH_BY_LANES(rem2d_toi_kernel);
         }
     }
+#undef LAUNCH_BY_LANES
+#undef LAUNCH_K
     HIP_TRY(hipGetLastError());
     return REM2D_OK;
 }

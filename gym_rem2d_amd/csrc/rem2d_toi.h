@@ -368,7 +368,9 @@ DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
 #define SCR_CC_BASE (KT * SCR_WORDS)
 #define SCR_TOI_BASE (KT * SCR_WORDS + KT * CC_WORDS)
 #define SCR_SWEEP_BASE (SCR_TOI_BASE + KC) // c0.x, c0.y, a0 handed from the step kernel to the TOI kernel
-#define SCR_TOTAL_WORDS (SCR_SWEEP_BASE + 3)
+#define SCR_MISC_BASE (SCR_SWEEP_BASE + 3)  // split pipeline: [0] nTouch | solve << 8, [1] pair-slot map of the touching contacts
+#define SCR_JREC_BASE (SCR_MISC_BASE + 2)   // split pipeline: joint lever arms rA.x rA.y rB.x rB.y
+#define SCR_TOTAL_WORDS (SCR_JREC_BASE + 4)
 
 struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, events; };
 
