@@ -223,23 +223,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel (the lane bucket with the most device time)
+    # roofline of the dominant kernel: the merged step kernel over all lane buckets (its time is booked on the
+    # first world), or the lane bucket with the most device time when every bucket is launched on its own
     kern = []
     for (w, _), m in zip(env.worlds, morphs):
         ms, launches = w.kernel_time_ms()
         w.enable_timing(False)
         kern.append((ms, launches, m))
-    ms, launches, m = max(kern, key=lambda k: k[0])
-    bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
+    merged = len(env.worlds) > 1 and env.merged_launch
+    if merged:
+        ms, launches = kern[0][0], kern[0][1]
+        bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
+        flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))
+        kname = "rem2d_step_multi_kernel"
+    else:
+        ms, launches, m = max(kern, key=lambda k: k[0])
+        bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
+        flops_per_step = float(valu_flops_per_env_step(m.n_bodies).sum())
+        kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % m.lanes
     steps_per_launch_avg = args.steps / max(1, launches)
     avg_ms = ms / max(1, launches)
     achieved = bytes_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     err = int(env.errors().max())
-    kname = "rem2d_step_kernel<%d>" % m.lanes
     traffic_bytes, traffic_src = (pmc_traffic(kname) if (args.workload == "lsystem" and not args.discrete and n_envs == 65536)
                                   else (None, None))
     traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
-    valu = float(valu_flops_per_env_step(m.n_bodies).sum()) * steps_per_launch_avg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    valu = flops_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
 
     if rank == 0:
         out = {

@@ -16,6 +16,7 @@ FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
 
 CONTACT_SLOTS = 24
+MAX_WORLDS_PER_STEP = 8
 SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
@@ -97,6 +98,9 @@ def lib():
     L.rem2d_world_reset.argtypes = [C.c_void_p, C.POINTER(Morph), C.c_void_p]
     L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
+    L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
+    L.rem2d_worlds_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
+                                       C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]

@@ -69,6 +69,7 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_narrowphase.h"
 #include "rem2d_solver.h"
 #include "rem2d_toi.h"
+#include "rem2d_position.h"
 #include "rem2d_kernels.h"
 #include "rem2d_pipeline.h"
 
@@ -155,10 +156,17 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->launches = 0;
     bind_state(w);
     w->S.scr = nullptr;
-    hipError_t e = hipMalloc((void **)&w->S.scr, (size_t)SCR_TOTAL_WORDS * L.Lp * sizeof(float));
+    hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
     if (e != hipSuccess) {
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    }
+    w->S.toiWork = (int *)(w->S.scr + (size_t)SCR_TOTAL_WORDS * L.Lp);
+    e = hipMemset(w->S.toiWork, 0, 64 * sizeof(int));
+    if (e != hipSuccess) {
+        (void)hipFree(w->S.scr);
+        delete w;
+        return fail(REM2D_E_HIP, std::string("hipMemset(scratch): ") + hipGetErrorString(e));
     }
     *out = w;
     return REM2D_OK;
@@ -325,10 +333,11 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
     const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    // REM2D_PIPELINE=0 selects the fused rem2d_step_kernel (one launch for all of Modular2D.step), the
-    // default is the split pipeline pre -> vel -> post whose velocity kernel maps lanes to constraints.
-    static const bool splitEnv = !(getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 0);
-    const bool split = splitEnv && pos_iters <= 64; // the pipelined position solver tracks iterations in a 64-bit mask
+    // Default: the fused rem2d_step_kernel (one launch for all of Modular2D.step).  REM2D_PIPELINE=1 selects
+    // the split pipeline pre -> vel -> post whose velocity kernel maps lanes to constraints: fewer
+    // instructions, but bound by the barrier-to-barrier latency of its slots -- measured slower so far.
+    static const bool splitEnv = getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 1;
+    const bool split = splitEnv;
     StepArgs A;
     A.nSteps = (continuous || split) ? 1 : n_steps;
     A.dt = dt;
@@ -389,13 +398,78 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
         }
         if (w->timing) w->pending.emplace_back(e0, e1);
         if (continuous) {
-            LAUNCH_BY_LANES(rem2d_toi_kernel);
+            LAUNCH_BY_LANES(rem2d_toi_scan_kernel);
+            LAUNCH_BY_LANES(rem2d_toi_heavy_kernel);
         }
     }
 #undef LAUNCH_BY_LANES
 #undef LAUNCH_K
     HIP_TRY(hipGetLastError());
     return REM2D_OK;
+}
+extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
+                                    int32_t pos_iters, void *stream) {
+    if (!ws || n_worlds <= 0) return fail(REM2D_E_INVALID, "no worlds");
+    if (n_worlds == 1) return rem2d_world_step_ex(ws[0], n_steps, dt, vel_iters, pos_iters, stream);
+    if (n_worlds > REM2D_MAX_WORLDS_PER_STEP) return fail(REM2D_E_INVALID, "too many worlds for one launch");
+    static_assert(REM2D_MAX_WORLDS_PER_STEP == REM2D_MAX_BATCH, "batch size");
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    unsigned blocks = 0;
+    for (int i = 0; i < n_worlds; ++i) {
+        rem2d_world *w = ws[i];
+        if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+        if (!w->haveTerrain) return fail(REM2D_E_STATE, "rem2d_world_set_terrain must be called before step");
+        if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
+        if (w->cfg.device != ws[0]->cfg.device) return fail(REM2D_E_INVALID, "worlds of one launch must share the device");
+        if ((w->cfg.flags & REM2D_FLAG_CONTINUOUS) != (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS))
+            return fail(REM2D_E_INVALID, "worlds of one launch must agree on REM2D_FLAG_CONTINUOUS");
+        B.S[i] = w->S;
+        B.T[i] = w->T;
+        B.lanes[i] = w->cfg.lanes;
+        blocks += (unsigned)w->L.Lp / WAVE;
+        B.blockEnd[i] = blocks;
+    }
+    B.n = n_worlds;
+    if (n_steps <= 0) return REM2D_OK;
+    rem2d_world *w0 = ws[0];
+    HIP_TRY(hipSetDevice(w0->cfg.device));
+    const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
+    StepArgs A;
+    A.nSteps = continuous ? 1 : n_steps;
+    A.dt = dt;
+    A.velIters = vel_iters;
+    A.posIters = pos_iters;
+    A.defer = continuous ? 1 : 0;
+    dim3 grid(blocks), block(WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    // the merged kernel's 3-waves/SIMD build spills in every lane-count variant; 2 waves/SIMD measured faster
+    static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
+    const bool three = forced == 3;
+    const int launches = continuous ? n_steps : 1;
+    for (int l = 0; l < launches; ++l) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (w0->timing) {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, st));
+        }
+        if (three) hipLaunchKernelGGL(rem2d_step_multi_kernel<3>, grid, block, 0, st, B, A);
+        else hipLaunchKernelGGL(rem2d_step_multi_kernel<2>, grid, block, 0, st, B, A);
+        if (w0->timing) {
+            HIP_TRY(hipEventRecord(e1, st));
+            w0->pending.emplace_back(e0, e1);
+        }
+        if (continuous) {
+            hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
+            hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
+extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, void *stream) {
+    return rem2d_worlds_step_ex(ws, n_worlds, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream);
 }
 extern "C" int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream) {
     // Modular2DEnv.py:634  self.world.Step(1.0/FPS, 6*30, 2*30)

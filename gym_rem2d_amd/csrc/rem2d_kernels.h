@@ -37,12 +37,13 @@ struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TO
 // HBM/L2 at its point of use once per step, so that the kernel fits two waves per SIMD.
 // W = waves per SIMD the register allocation targets: 2 (238 VGPRs, no spills) or 3 (168 VGPRs, ~95 spilled
 // outside the velocity loop); 3 pays off only when the launch has enough waves to fill the extra slots.
-template <int K, int W>
-__global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ float mbox[3][WAVE]; // velocity / position mailbox for joint rounds
+template <int K>
+DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
+    // psh.mbox: velocity mailbox of the joint slots; the rest of psh: position solver
     const int lane = threadIdx.x;
-    const unsigned gl0 = blockIdx.x * WAVE + lane;
+    const unsigned gl0 = block * WAVE + lane;
     const unsigned env0 = gl0 / K;
+    if (gl0 == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
     unsigned gl = gl0, env = env0;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
@@ -236,25 +237,25 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
                 }
             }
             if (nRounds > 0) {
-                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                psh.mbox[0][lane] = vx; psh.mbox[1][lane] = vy; psh.mbox[2][lane] = w;
                 lds_sync();
                 for (int r = 0; r < nRounds; ++r) {
                     if (jround == r) {
-                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
-                        float wA = mbox[2][pl];
-                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
-                        float wB = mbox[2][lane];
+                        V2 vA = mk(psh.mbox[0][pl], psh.mbox[1][pl]);
+                        float wA = psh.mbox[2][pl];
+                        V2 vB = mk(psh.mbox[0][lane], psh.mbox[1][lane]);
+                        float wB = psh.mbox[2][lane];
                         V2 P = mk(impX, impY);
                         vA = vsub(vA, vscale(mA, P));
                         wA -= iA * (vcross(rA, P) + motorImp + impZ);
                         vB = vadd(vB, vscale(mB, P));
                         wB += iB * (vcross(rB, P) + motorImp + impZ);
-                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
-                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
+                        psh.mbox[0][pl] = vA.x; psh.mbox[1][pl] = vA.y; psh.mbox[2][pl] = wA;
+                        psh.mbox[0][lane] = vB.x; psh.mbox[1][lane] = vB.y; psh.mbox[2][lane] = wB;
                     }
                     lds_sync();
                 }
-                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
+                vx = psh.mbox[0][lane]; vy = psh.mbox[1][lane]; w = psh.mbox[2][lane];
             }
             // ---- velocity iterations, software-pipelined across iterations ----
             // One tick = a joint slot then a contact slot.  Joint (parent, this body) of iteration t fires
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
             // `period` (2..4) slots per iteration instead of J.  Velocities live in the LDS mailbox.
             {
                 const int iters = A.velIters;
-                mbox[0][lane] = vx; mbox[1][lane] = vy; mbox[2][lane] = w;
+                psh.mbox[0][lane] = vx; psh.mbox[1][lane] = vy; psh.mbox[2][lane] = w;
                 lds_sync();
                 int nextJ = (hasJoint && iters > 0) ? jround : 0x7fffffff, leftJ = iters;
                 int nextC = (active && nTouch > 0 && iters > 0) ? offC : 0x7fffffff, leftC = iters;
@@ -272,10 +273,10 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
                 for (int tick = 0; tick < nTicks; ++tick) {
                     if (tick == nextJ) {
                         nextJ = (--leftJ > 0) ? nextJ + period : 0x7fffffff;
-                        V2 vA = mk(mbox[0][pl], mbox[1][pl]);
-                        float wA = mbox[2][pl];
-                        V2 vB = mk(mbox[0][lane], mbox[1][lane]);
-                        float wB = mbox[2][lane];
+                        V2 vA = mk(psh.mbox[0][pl], psh.mbox[1][pl]);
+                        float wA = psh.mbox[2][pl];
+                        V2 vB = mk(psh.mbox[0][lane], psh.mbox[1][lane]);
+                        float wB = psh.mbox[2][lane];
                         // motor
                         if (limitState != LIM_EQUAL) {
                             float Cdot = wB - wA - motorSpeed;
@@ -327,13 +328,13 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
                             vB = vadd(vB, vscale(mB, impulse));
                             wB += iB * vcross(rB, impulse);
                         }
-                        mbox[0][pl] = vA.x; mbox[1][pl] = vA.y; mbox[2][pl] = wA;
-                        mbox[0][lane] = vB.x; mbox[1][lane] = vB.y; mbox[2][lane] = wB;
+                        psh.mbox[0][pl] = vA.x; psh.mbox[1][pl] = vA.y; psh.mbox[2][pl] = wA;
+                        psh.mbox[0][lane] = vB.x; psh.mbox[1][lane] = vB.y; psh.mbox[2][lane] = wB;
                     }
                     lds_sync();
                     if (tick == nextC) { // contacts of this body, in list order
                         nextC = (--leftC > 0) ? nextC + period : 0x7fffffff;
-                        float cvx = mbox[0][lane], cvy = mbox[1][lane], cw = mbox[2][lane];
+                        float cvx = psh.mbox[0][lane], cvy = psh.mbox[1][lane], cw = psh.mbox[2][lane];
 #pragma unroll
                         for (int t = 0; t < KR; ++t)
                             if (t < nTouch) contact_solve(cc[t], mB, iB, friction, cvx, cvy, cw);
@@ -346,11 +347,11 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
                                 SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
                             }
                         }
-                        mbox[0][lane] = cvx; mbox[1][lane] = cvy; mbox[2][lane] = cw;
+                        psh.mbox[0][lane] = cvx; psh.mbox[1][lane] = cvy; psh.mbox[2][lane] = cw;
                     }
                     lds_sync();
                 }
-                vx = mbox[0][lane]; vy = mbox[1][lane]; w = mbox[2][lane];
+                vx = psh.mbox[0][lane]; vy = psh.mbox[1][lane]; w = psh.mbox[2][lane];
             }
             // ---- StoreImpulses ----
 #pragma unroll
@@ -395,126 +396,11 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
                 ang += h * w;
                 vx = v.x; vy = v.y;
             }
-            // ---- position iterations (per creature early exit) ----
+            // ---- position iterations (per creature early exit), software-pipelined with roll-back ----
             bool envSolved = false;
             int itersUsed = A.posIters;
-            {
-                const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
-                const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
-                for (int it = 0; it < A.posIters; ++it) {
-                    float minSeparation = 0.0f;
-                    if (!envSolved && active) {
-                        for (int t = 0; t < nTouch; ++t) {
-                            const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
-                            int tc = __float_as_int(SW(sb, 0));
-                            int mtype = tc & 0xff, mcount = tc >> 8;
-                            V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
-                            const float radiusA = B2_POLYGON_RADIUS;
-                            for (int j = 0; j < mcount; ++j) {
-                                V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
-                                V2 cB = mk(px, py);
-                                V2 normal, point;
-                                float separation;
-                                Rot qB = rot_set(ang);
-                                if (mtype == MF_CIRCLES) {
-                                    V2 pointA = lp;
-                                    V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
-                                    normal = vsub(pointB, pointA);
-                                    vnormalize(normal);
-                                    point = vscale(0.5f, vadd(pointA, pointB));
-                                    separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                                } else if (mtype == MF_FACE_A) {
-                                    normal = ln;
-                                    V2 planePoint = lp;
-                                    V2 clipPoint = xmul(qB, cB, pj);
-                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                    point = clipPoint;
-                                } else {
-                                    normal = rmul(qB, ln);
-                                    V2 planePoint = xmul(qB, cB, lp);
-                                    V2 clipPoint = pj;
-                                    separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                                    point = clipPoint;
-                                    normal = vneg(normal);
-                                }
-                                V2 rBp = vsub(point, cB);
-                                minSeparation = fmin32(minSeparation, separation);
-                                float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                                float rnB = vcross(rBp, normal);
-                                float Kn = mB + iB * rnB * rnB;
-                                float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                                V2 P = vscale(impulse, normal);
-                                px = px + mB * P.x;
-                                py = py + mB * P.y;
-                                ang += iB * vcross(rBp, P);
-                            }
-                        }
-                    }
-                    int jointOk = 1;
-                    if (nRounds > 0) {
-                        mbox[0][lane] = px; mbox[1][lane] = py; mbox[2][lane] = ang;
-                        lds_sync();
-                        for (int r = 0; r < nRounds; ++r) {
-                            if (jround == r && !envSolved) {
-                                V2 cA = mk(mbox[0][pl], mbox[1][pl]);
-                                float aA = mbox[2][pl];
-                                V2 cB = mk(mbox[0][lane], mbox[1][lane]);
-                                float aB = mbox[2][lane];
-                                float angularError = 0.0f, positionError = 0.0f;
-                                if (limitState != LIM_INACTIVE) {
-                                    float angle = aB - aA - 0.0f;
-                                    float limitImpulse = 0.0f;
-                                    if (limitState == LIM_EQUAL) {
-                                        float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
-                                        limitImpulse = -motorMass * C;
-                                        angularError = fabs32(C);
-                                    } else if (limitState == LIM_AT_LOWER) {
-                                        float C = angle - jLower;
-                                        angularError = -C;
-                                        C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
-                                        limitImpulse = -motorMass * C;
-                                    } else {
-                                        float C = angle - jUpper;
-                                        angularError = C;
-                                        C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
-                                        limitImpulse = -motorMass * C;
-                                    }
-                                    aA -= iA * limitImpulse;
-                                    aB += iB * limitImpulse;
-                                }
-                                {
-                                    Rot qA = rot_set(aA), qB = rot_set(aB);
-                                    V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
-                                    V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
-                                    V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
-                                    positionError = vlen(C);
-                                    float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
-                                    float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
-                                    float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
-                                    float det = Kexx * Keyy - Kexy * Kexy;
-                                    if (det != 0.0f) det = 1.0f / det;
-                                    V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
-                                    V2 impulse = vneg(sol);
-                                    cA = vsub(cA, vscale(mA, impulse));
-                                    aA -= iA * vcross(prA, impulse);
-                                    cB = vadd(cB, vscale(mB, impulse));
-                                    aB += iB * vcross(prB, impulse);
-                                }
-                                mbox[0][pl] = cA.x; mbox[1][pl] = cA.y; mbox[2][pl] = aA;
-                                mbox[0][lane] = cB.x; mbox[1][lane] = cB.y; mbox[2][lane] = aB;
-                                jointOk = positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP;
-                            }
-                            lds_sync();
-                        }
-                        px = mbox[0][lane]; py = mbox[1][lane]; ang = mbox[2][lane];
-                    }
-                    float envMinSep = group_min<K>(minSeparation);
-                    int envJointsOk = group_and<K>(jointOk);
-                    bool okNow = (envMinSep >= -3.0f * B2_LINEAR_SLOP) && envJointsOk;
-                    if (!envSolved && okNow) { envSolved = true; itersUsed = it + 1; }
-                    if (__all(envSolved ? 1 : 0)) break;
-                }
-            }
+            solve_positions_pipelined<K>(S, psh, gl, lane, pl, active, hasJoint, jround, period, nTouch, mA, iA, mB, iB, radiusB,
+                                         limitState, motorMass, A.posIters, px, py, ang, envSolved, itersUsed);
             lastPosIters = itersUsed;
             // ---- sleep ----
             if (allowSleep) {
@@ -580,35 +466,139 @@ __global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T,
     }
 }
 
+template <int K, int W>
+__global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
+    __shared__ PosShared psh;
+    step_body<K>(S, T, A, blockIdx.x, psh);
+}
+
+// ---- several worlds (lane buckets of one population) in ONE launch ----
+// Kernels of different worlds launched on different streams barely overlap: a big bucket's grid owns every
+// wave slot (the register file is the limit) and the small buckets then run almost alone, latency bound.
+// One grid over the blocks of all worlds lets the dispatcher pack them: block -> world by prefix sums.
+#define REM2D_MAX_BATCH 8
+struct Batch {
+    State S[REM2D_MAX_BATCH];
+    Terrain T[REM2D_MAX_BATCH];
+    unsigned blockEnd[REM2D_MAX_BATCH]; // exclusive prefix sums of the worlds' block counts
+    int lanes[REM2D_MAX_BATCH];
+    int n;
+};
+DEV int batch_find(const Batch &B, unsigned &block) {
+    int b = 0;
+    while (b + 1 < B.n && block >= B.blockEnd[b]) ++b;
+    if (b > 0) block -= B.blockEnd[b - 1];
+    return b;
+}
+#define BATCH_DISPATCH(BODY, ...)                                 \
+    switch (B.lanes[b]) {                                         \
+    case 2: BODY<2>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break;   \
+    case 4: BODY<4>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break;   \
+    case 8: BODY<8>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break;   \
+    case 16: BODY<16>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break; \
+    case 32: BODY<32>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break; \
+    default: BODY<64>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break; \
+    }
+template <int W>
+__global__ __launch_bounds__(WAVE, W) void rem2d_step_multi_kernel(Batch B, StepArgs A) {
+    __shared__ PosShared psh;
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(step_body, psh)
+}
+
 // =====================================================================================
-// TOI kernel: b2World::SolveTOI for every lane, then the per-step bookkeeping.  Launched after
-// rem2d_step_kernel (nSteps = 1, defer = 1) when REM2D_FLAG_CONTINUOUS is set; kept out of the
-// step kernel so that its branchy GJK / root-finder code does not share a register allocation
-// with the velocity loop.
+// TOI kernels: b2World::SolveTOI, then the per-step bookkeeping.  Launched after the step (or post)
+// kernel when REM2D_FLAG_CONTINUOUS is set; kept out of the step kernel so that the branchy GJK /
+// root-finder code does not share a register allocation with the velocity loop.
+//
+//   rem2d_toi_scan_kernel   lane = body.  Invalidates last step's TOI flags and applies the two exact
+//                           early-outs (toi_far_apart) to every pair.  A body all of whose pairs are far
+//                           apart has alpha = 1 everywhere: SolveTOI leaves it untouched.  The others
+//                           (a few per cent: bodies that are landing or sliding into an edge) are appended
+//                           to a work list.  Light (no GJK), so it runs at high occupancy over its
+//                           memory latency.
+//   rem2d_toi_heavy_kernel  lane = work-list entry: the full solve_toi_lane for that body, i.e. dense
+//                           wavefronts of bodies that really need b2TimeOfImpact / TOI sub-steps instead
+//                           of one such lane per wavefront.  Bodies are independent (terrain sweeps are
+//                           time-transparent), so the list order does not matter.
+// reward / done / fitness only read the root body: whichever kernel finalises the root does the bookkeeping.
 // =====================================================================================
 template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_kernel(State S, Terrain T, StepArgs A) {
+DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
     const int lane = threadIdx.x;
-    const unsigned gl = blockIdx.x * WAVE + lane;
+    const unsigned gl = block * WAVE + lane;
     const unsigned env = gl / K;
-    const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
+    const unsigned Lp = S.Lp;
     const int shape = LI(L_SHAPE);
-    float px = LF(L_PX);
+    const float px = LF(L_PX);
+    bool heavy = false;
     if (shape != SHAPE_NONE && A.dt > 0.0f) {
-        const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
-        LaneBody B;
-        B.px = px; B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
-        B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
-        B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
-                           SW(wb, 2), B);
-        LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
-        LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
-        if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
-        if (B.err) atomicOr(&EI(E_ERR), B.err);
-        px = B.px;
+        const unsigned wb = (unsigned)SCR_SWEEP_BASE * Lp + gl;
+        Sweep sw;
+        sw.c0 = mk(SW(wb, 0), SW(wb, 1)); sw.a0 = SW(wb, 2);
+        sw.c = mk(px, LF(L_PY)); sw.a = LF(L_ANG);
+        const float hx = LF(L_HX), hy = LF(L_HY);
+        const int awake = LI(L_AWAKE), cCount = LI(L_CCOUNT);
+        const Proxy pB = proxy_body(shape, hx, hy);
+        const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f;
+        for (int s = 0; s < cCount; ++s) {
+            unsigned o = (unsigned)s * Lp + gl;
+            int info = CI(C_INFO, o) & (0xffff | CI_ENABLED); // m_stepComplete: invalidate TOIs
+            CI(C_INFO, o) = info;
+            if (!(info & CI_ENABLED) || !awake || heavy) continue;
+            int e = CI(C_EDGE, o);
+            Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
+            if (e < T.nPoly) { pA.v[2] = static_vert(T, e, 2); pA.v[3] = static_vert(T, e, 3); pA.count = 4; }
+            heavy = !toi_far_apart(pA, pB, sw, shape, hx, hy, coreR);
+        }
     }
-    env_bookkeeping(S, env, sub, __shfl(px, base));
+    if (heavy) {
+        int slot = atomicAdd(&S.toiWork[0], 1);
+        S.toiWork[16 + slot] = (int)gl;
+    } else if (sub == 0) {
+        env_bookkeeping(S, env, 0, px);
+    }
+}
+template <int K>
+DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
+    const unsigned idx = block * WAVE + threadIdx.x;
+    if (block * WAVE >= (unsigned)S.toiWork[0]) return;
+    if (idx >= (unsigned)S.toiWork[0]) return;
+    const unsigned gl = (unsigned)S.toiWork[16 + idx];
+    const unsigned env = gl / K;
+    const int shape = LI(L_SHAPE);
+    const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
+    LaneBody B;
+    B.px = LF(L_PX); B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
+    B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
+    B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
+                       SW(wb, 2), B);
+    LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
+    LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
+    if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
+    if (B.err) atomicOr(&EI(E_ERR), B.err);
+    if ((gl & (K - 1)) == 0) env_bookkeeping(S, env, 0, B.px);
+}
+
+template <int K>
+__global__ __launch_bounds__(WAVE) void rem2d_toi_scan_kernel(State S, Terrain T, StepArgs A) {
+    toi_scan_body<K>(S, T, A, blockIdx.x);
+}
+template <int K>
+__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_heavy_kernel(State S, Terrain T, StepArgs A) {
+    toi_heavy_body<K>(S, T, A, blockIdx.x);
+}
+__global__ __launch_bounds__(WAVE) void rem2d_toi_scan_multi_kernel(Batch B, StepArgs A) {
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(toi_scan_body)
+}
+__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_heavy_multi_kernel(Batch B, StepArgs A) {
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(toi_heavy_body)
 }
 
 // =====================================================================================

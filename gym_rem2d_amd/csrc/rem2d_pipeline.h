@@ -41,6 +41,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_pre_kernel(State S, Terrain T, Ste
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
     const unsigned Lp = S.Lp;
+    if (gl == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
 
     const int shape = LI(L_SHAPE);
     const bool active = shape != SHAPE_NONE;
@@ -530,209 +531,6 @@ __global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_kernel(State S, VelArgs
         const unsigned gl = wg0 + tid;
         LF(L_VX) = vel[0][tid]; LF(L_VY) = vel[1][tid]; LF(L_W) = vel[2][tid];
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// b2Island::Solve position iterations for the K-lane creatures of one wavefront, software-pipelined.
-//
-// Box2D: for it < posIters { contacts (per body, list order); joints (island order); if all within
-// tolerance: break }.  The joints of one iteration form a chain of `rounds` dependent steps, but joint k
-// of iteration n+1 only has to wait for the operations of iteration n that share one of its two bodies,
-// so iteration n+1 can start `period` ticks after iteration n (same modulo schedule as the velocity
-// iterations; one tick = a contact slot, then a joint slot; body b's contacts fire in the tick of its
-// first joint).  The catch is the exit test: whether iteration n was the last one is only known when its
-// last joint has run, by which time early joints of iterations n+1.. have already moved bodies.  Every
-// body therefore snapshots its position after its last operation of each iteration into a ring in LDS;
-// when iteration n passes the test the creature's bodies are rolled back to snapshot n -- exactly the
-// state Box2D leaves.  The effective period is raised so that at most POS_RING iterations are in flight.
-// A 60-iteration creature costs 60*period ticks instead of 60*rounds rounds (3x fewer for 16 modules).
-// ---------------------------------------------------------------------------------------------------
-#define POS_RING 8
-struct PosShared {
-    float mbox[3][WAVE];
-    float snap[POS_RING][3][WAVE];
-    int firstR[WAVE], lastR[WAVE];
-};
-template <int K> DEV int group_max(int v) {
-#pragma unroll
-    for (int o = 1; o < K; o <<= 1) {
-        int t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-template <int K>
-DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, int lane, int pl, bool active, bool hasJoint,
-                                   int jround, int period, int nTouch, float mA, float iA, float mB, float iB, float radiusB,
-                                   int limitState, float motorMass, int posIters, float &px, float &py, float &ang,
-                                   bool &envSolved, int &itersUsed) {
-    const unsigned Lp = S.Lp;
-    const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
-    const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
-    // first / last joint round of every body (its own joint and those of its children)
-    sh.firstR[lane] = 0x7fffffff;
-    sh.lastR[lane] = -1;
-    lds_sync();
-    if (hasJoint) {
-        atomicMin(&sh.firstR[lane], jround); atomicMax(&sh.lastR[lane], jround);
-        atomicMin(&sh.firstR[pl], jround); atomicMax(&sh.lastR[pl], jround);
-    }
-    lds_sync();
-    const int lastB = sh.lastR[lane];
-    const bool anyJoint = lastB >= 0;
-    const bool isLastA = hasJoint && jround == sh.lastR[pl], isLastB = hasJoint && jround == lastB;
-    const int maxR = group_max<K>(hasJoint ? jround : 0);
-    const int P = max(group_max<K>(period), maxR / POS_RING + 1); // >= 1; keeps <= POS_RING iterations in flight
-    const bool touching = active && nTouch > 0;
-    const bool hasOps = active && (anyJoint || nTouch > 0);
-    const bool run = posIters > 0 && posIters <= 64;
-    int nextC = (run && touching) ? (anyJoint ? sh.firstR[lane] : 0) : 0x7fffffff, leftC = posIters, itC = 0;
-    int nextJ = (run && hasJoint) ? jround : 0x7fffffff, leftJ = posIters, itJ = 0;
-    int nextD = run ? maxR : 0x7fffffff, itD = 0;
-    unsigned long long failBits = 0ull;
-    const int lastTick = wave_max(run ? maxR + (posIters - 1) * P : -1);
-    sh.mbox[0][lane] = px; sh.mbox[1][lane] = py; sh.mbox[2][lane] = ang;
-    lds_sync();
-    for (int tick = 0; tick <= lastTick; ++tick) {
-        // ---- contact slot: b2ContactSolver::SolvePositionConstraints for this body's manifolds ----
-        if (tick == nextC) {
-            float cx = sh.mbox[0][lane], cy = sh.mbox[1][lane], ca = sh.mbox[2][lane];
-            float minSeparation = 0.0f;
-            for (int t = 0; t < nTouch; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
-                int mtype = tc & 0xff, mcount = tc >> 8;
-                V2 lnrm = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
-                const float radiusA = B2_POLYGON_RADIUS;
-                for (int j = 0; j < mcount; ++j) {
-                    V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
-                    V2 cB = mk(cx, cy);
-                    V2 normal, point;
-                    float separation;
-                    Rot qB = rot_set(ca);
-                    if (mtype == MF_CIRCLES) {
-                        V2 pointA = lp;
-                        V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
-                        normal = vsub(pointB, pointA);
-                        vnormalize(normal);
-                        point = vscale(0.5f, vadd(pointA, pointB));
-                        separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                    } else if (mtype == MF_FACE_A) {
-                        normal = lnrm;
-                        V2 planePoint = lp;
-                        V2 clipPoint = xmul(qB, cB, pj);
-                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                    } else {
-                        normal = rmul(qB, lnrm);
-                        V2 planePoint = xmul(qB, cB, lp);
-                        V2 clipPoint = pj;
-                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                        normal = vneg(normal);
-                    }
-                    V2 rBp = vsub(point, cB);
-                    minSeparation = fmin32(minSeparation, separation);
-                    float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                    float rnB = vcross(rBp, normal);
-                    float Kn = mB + iB * rnB * rnB;
-                    float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                    V2 Pc = vscale(impulse, normal);
-                    cx = cx + mB * Pc.x;
-                    cy = cy + mB * Pc.y;
-                    ca += iB * vcross(rBp, Pc);
-                }
-            }
-            if (!(minSeparation >= -3.0f * B2_LINEAR_SLOP)) failBits |= 1ull << itC;
-            sh.mbox[0][lane] = cx; sh.mbox[1][lane] = cy; sh.mbox[2][lane] = ca;
-            if (!anyJoint) { // the contact slot is this body's last operation of the iteration
-                const int r = itC & (POS_RING - 1);
-                sh.snap[r][0][lane] = cx; sh.snap[r][1][lane] = cy; sh.snap[r][2][lane] = ca;
-            }
-            ++itC;
-            nextC = (--leftC > 0) ? nextC + P : 0x7fffffff;
-        }
-        lds_sync();
-        // ---- joint slot: b2RevoluteJoint::SolvePositionConstraints ----
-        if (tick == nextJ) {
-            V2 cA = mk(sh.mbox[0][pl], sh.mbox[1][pl]);
-            float aA = sh.mbox[2][pl];
-            V2 cB = mk(sh.mbox[0][lane], sh.mbox[1][lane]);
-            float aB = sh.mbox[2][lane];
-            float angularError = 0.0f, positionError = 0.0f;
-            if (limitState != LIM_INACTIVE) {
-                float angle = aB - aA - 0.0f;
-                float limitImpulse = 0.0f;
-                if (limitState == LIM_EQUAL) {
-                    float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
-                    limitImpulse = -motorMass * C;
-                    angularError = fabs32(C);
-                } else if (limitState == LIM_AT_LOWER) {
-                    float C = angle - jLower;
-                    angularError = -C;
-                    C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
-                    limitImpulse = -motorMass * C;
-                } else {
-                    float C = angle - jUpper;
-                    angularError = C;
-                    C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
-                    limitImpulse = -motorMass * C;
-                }
-                aA -= iA * limitImpulse;
-                aB += iB * limitImpulse;
-            }
-            {
-                Rot qA = rot_set(aA), qB = rot_set(aB);
-                V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
-                V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
-                V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
-                positionError = vlen(C);
-                float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
-                float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
-                float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
-                float det = Kexx * Keyy - Kexy * Kexy;
-                if (det != 0.0f) det = 1.0f / det;
-                V2 sol = mk(det * (Keyy * C.x - Kexy * C.y), det * (Kexx * C.y - Kexy * C.x));
-                V2 impulse = vneg(sol);
-                cA = vsub(cA, vscale(mA, impulse));
-                aA -= iA * vcross(prA, impulse);
-                cB = vadd(cB, vscale(mB, impulse));
-                aB += iB * vcross(prB, impulse);
-            }
-            sh.mbox[0][pl] = cA.x; sh.mbox[1][pl] = cA.y; sh.mbox[2][pl] = aA;
-            sh.mbox[0][lane] = cB.x; sh.mbox[1][lane] = cB.y; sh.mbox[2][lane] = aB;
-            if (!(positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP)) failBits |= 1ull << itJ;
-            const int r = itJ & (POS_RING - 1);
-            if (isLastA) { sh.snap[r][0][pl] = cA.x; sh.snap[r][1][pl] = cA.y; sh.snap[r][2][pl] = aA; }
-            if (isLastB) { sh.snap[r][0][lane] = cB.x; sh.snap[r][1][lane] = cB.y; sh.snap[r][2][lane] = aB; }
-            ++itJ;
-            nextJ = (--leftJ > 0) ? nextJ + P : 0x7fffffff;
-        }
-        lds_sync();
-        // ---- verdict on the iteration whose last joint has just run (creature-uniform) ----
-        const bool due = tick == nextD;
-        const int failed = group_or<K>(due ? (int)((failBits >> itD) & 1ull) : 0);
-        bool restored = false;
-        if (due) {
-            if (!failed) { // Box2D breaks here: drop whatever later iterations have already done
-                envSolved = true;
-                itersUsed = itD + 1;
-                nextC = nextJ = nextD = 0x7fffffff;
-                if (hasOps) {
-                    const int r = itD & (POS_RING - 1);
-                    sh.mbox[0][lane] = sh.snap[r][0][lane]; sh.mbox[1][lane] = sh.snap[r][1][lane];
-                    sh.mbox[2][lane] = sh.snap[r][2][lane];
-                    restored = true;
-                }
-            } else {
-                ++itD;
-                nextD = itD < posIters ? nextD + P : 0x7fffffff;
-            }
-        }
-        if (__any(restored ? 1 : 0)) lds_sync();
-        if (__all(nextD == 0x7fffffff ? 1 : 0)) break;
-    }
-    px = sh.mbox[0][lane]; py = sh.mbox[1][lane]; ang = sh.mbox[2][lane];
 }
 
 // ---------------------------------------------------------------------------------------------------

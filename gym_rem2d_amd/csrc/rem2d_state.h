@@ -79,6 +79,7 @@ struct Terrain { // static bodies at the origin, in creation (= broadphase proxy
 struct State {
     char *lane4, *lane8, *slot4, *env4, *env8; // group bases inside the caller's arena
     float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
+    int *toiWork;                              // handle-owned: [0] count, [16..16+Lp) bodies that need the full TOI solve
     unsigned Lp, Np, nEnvs, flags;
 };
 // accessors (S, gl and env must be in scope where they are used)

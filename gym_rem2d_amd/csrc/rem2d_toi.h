@@ -372,6 +372,84 @@ DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
 #define SCR_JREC_BASE (SCR_MISC_BASE + 2)   // split pipeline: joint lever arms rA.x rA.y rB.x rB.y
 #define SCR_TOTAL_WORDS (SCR_JREC_BASE + 4)
 
+// Exact early-outs of the TOI query for (static proxy pA, this body's proxy pB swept by sw): true means
+// b2TimeOfImpact would answer "separated" (alpha = 1) without it having to run.
+DEV bool toi_far_apart(const Proxy &pA, const Proxy &pB, const Sweep &sw, int shape, float hx, float hy, float coreR) {
+    // Conservative exact skip.  b2TimeOfImpact can only answer e_touching if some core-shape
+    // distance / separation it evaluates for t in [0,1] falls below target + tolerance, and every
+    // such value is >= the true distance of the core shapes at that t.  The body's core stays inside
+    // the disk of radius coreR around its centre, which moves on the segment c0 -> c: if that
+    // capsule's bounding box keeps more than target + tolerance (+ 5 mm for rounding) away from
+    // the static shape's bounding box, the answer is alpha = 1 without running GJK.
+    bool farApart;
+    {
+        V2 slo = pA.v[0], shi = pA.v[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < pA.count) { slo = vmin2(slo, pA.v[k]); shi = vmax2(shi, pA.v[k]); }
+        V2 blo = vsub(vmin2(sw.c0, sw.c), mk(coreR, coreR)), bhi = vadd(vmax2(sw.c0, sw.c), mk(coreR, coreR));
+        float gap = fmax32(fmax32(blo.x - shi.x, slo.x - bhi.x), fmax32(blo.y - shi.y, slo.y - bhi.y));
+        float totalRadius = pA.radius + pB.radius;
+        float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
+        const float need = target + 0.25f * B2_LINEAR_SLOP;
+        farApart = gap > need + 0.005f;
+        if (!farApart) {
+            // Second bound (catches resting contacts): any separating axis gives a lower bound lb0 of the
+            // core distance at the sweep start, and no point of the body moves further than
+            // |c - c0| + coreR * |a - a0| during the sweep, so distance(t) >= lb0 - that.  Axes tried:
+            // the static shape's face normals and the body's own axes.
+            Rot q0 = rot_set(sw.a0);
+            float lb0 = -FLT_MAX;
+            V2 bv[4];
+            const int nb = pB.count;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bv[k] = xmul(q0, sw.c0, pB.v[k < nb ? k : 0]);
+            if (pA.count == 2) { // edge: +-normal, and the edge direction beyond either end
+                V2 e = vsub(pA.v[1], pA.v[0]);
+                vnormalize(e);
+                V2 n = mk(e.y, -e.x);
+                float lo = FLT_MAX, hi = -FLT_MAX, tlo = FLT_MAX, thi = -FLT_MAX;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float d = vdot(n, vsub(bv[k], pA.v[0]));
+                    lo = fmin32(lo, d); hi = fmax32(hi, d);
+                    float td = vdot(e, vsub(bv[k], pA.v[0]));
+                    tlo = fmin32(tlo, td); thi = fmax32(thi, td);
+                }
+                float elen = vdot(e, vsub(pA.v[1], pA.v[0]));
+                lb0 = fmax32(fmax32(lo, -hi), fmax32(tlo - elen, -thi));
+            } else { // static box: its four face normals
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    V2 a = pA.v[i], b2 = pA.v[(i + 1) & 3];
+                    V2 ed = vsub(b2, a);
+                    vnormalize(ed);
+                    V2 n = mk(ed.y, -ed.x);
+                    float lo = FLT_MAX;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lo = fmin32(lo, vdot(n, vsub(bv[k], a)));
+                    lb0 = fmax32(lb0, lo);
+                }
+            }
+            if (shape == SHAPE_BOX) { // the body's axes against the static shape's vertices
+                float xlo = FLT_MAX, xhi = -FLT_MAX, ylo = FLT_MAX, yhi = -FLT_MAX;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < pA.count) {
+                        V2 l = rmulT(q0, vsub(pA.v[k], sw.c0));
+                        xlo = fmin32(xlo, l.x); xhi = fmax32(xhi, l.x);
+                        ylo = fmin32(ylo, l.y); yhi = fmax32(yhi, l.y);
+                    }
+                }
+                lb0 = fmax32(lb0, fmax32(fmax32(xlo - hx, -xhi - hx), fmax32(ylo - hy, -yhi - hy)));
+            }
+            float maxDisp = vlen(vsub(sw.c, sw.c0)) + coreR * fabs32(sw.a - sw.a0);
+            farApart = lb0 - maxDisp > need + 0.002f;
+        }
+    }
+    return farApart;
+}
+
 struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, events; };
 
 // b2World::SolveTOI restricted to this lane's body (see the section comment above).
@@ -407,78 +485,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 int e = CI(C_EDGE, o);
                 Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
                 if (e < T.nPoly) { pA.v[2] = static_vert(T, e, 2); pA.v[3] = static_vert(T, e, 3); pA.count = 4; }
-                // Conservative exact skip.  b2TimeOfImpact can only answer e_touching if some core-shape
-                // distance / separation it evaluates for t in [0,1] falls below target + tolerance, and every
-                // such value is >= the true distance of the core shapes at that t.  The body's core stays inside
-                // the disk of radius coreR around its centre, which moves on the segment c0 -> c: if that
-                // capsule's bounding box keeps more than target + tolerance (+ 5 mm for rounding) away from
-                // the static shape's bounding box, the answer is alpha = 1 without running GJK.
-                bool farApart;
-                {
-                    V2 slo = pA.v[0], shi = pA.v[0];
-#pragma unroll
-                    for (int k = 1; k < 4; ++k)
-                        if (k < pA.count) { slo = vmin2(slo, pA.v[k]); shi = vmax2(shi, pA.v[k]); }
-                    V2 blo = vsub(vmin2(sw.c0, sw.c), mk(coreR, coreR)), bhi = vadd(vmax2(sw.c0, sw.c), mk(coreR, coreR));
-                    float gap = fmax32(fmax32(blo.x - shi.x, slo.x - bhi.x), fmax32(blo.y - shi.y, slo.y - bhi.y));
-                    float totalRadius = pA.radius + pB.radius;
-                    float target = fmax32(B2_LINEAR_SLOP, totalRadius - 3.0f * B2_LINEAR_SLOP);
-                    const float need = target + 0.25f * B2_LINEAR_SLOP;
-                    farApart = gap > need + 0.005f;
-                    if (!farApart) {
-                        // Second bound (catches resting contacts): any separating axis gives a lower bound lb0 of the
-                        // core distance at the sweep start, and no point of the body moves further than
-                        // |c - c0| + coreR * |a - a0| during the sweep, so distance(t) >= lb0 - that.  Axes tried:
-                        // the static shape's face normals and the body's own axes.
-                        Rot q0 = rot_set(sw.a0);
-                        float lb0 = -FLT_MAX;
-                        V2 bv[4];
-                        const int nb = pB.count;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) bv[k] = xmul(q0, sw.c0, pB.v[k < nb ? k : 0]);
-                        if (pA.count == 2) { // edge: +-normal, and the edge direction beyond either end
-                            V2 e = vsub(pA.v[1], pA.v[0]);
-                            vnormalize(e);
-                            V2 n = mk(e.y, -e.x);
-                            float lo = FLT_MAX, hi = -FLT_MAX, tlo = FLT_MAX, thi = -FLT_MAX;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float d = vdot(n, vsub(bv[k], pA.v[0]));
-                                lo = fmin32(lo, d); hi = fmax32(hi, d);
-                                float td = vdot(e, vsub(bv[k], pA.v[0]));
-                                tlo = fmin32(tlo, td); thi = fmax32(thi, td);
-                            }
-                            float elen = vdot(e, vsub(pA.v[1], pA.v[0]));
-                            lb0 = fmax32(fmax32(lo, -hi), fmax32(tlo - elen, -thi));
-                        } else { // static box: its four face normals
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                V2 a = pA.v[i], b2 = pA.v[(i + 1) & 3];
-                                V2 ed = vsub(b2, a);
-                                vnormalize(ed);
-                                V2 n = mk(ed.y, -ed.x);
-                                float lo = FLT_MAX;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) lo = fmin32(lo, vdot(n, vsub(bv[k], a)));
-                                lb0 = fmax32(lb0, lo);
-                            }
-                        }
-                        if (shape == SHAPE_BOX) { // the body's axes against the static shape's vertices
-                            float xlo = FLT_MAX, xhi = -FLT_MAX, ylo = FLT_MAX, yhi = -FLT_MAX;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (k < pA.count) {
-                                    V2 l = rmulT(q0, vsub(pA.v[k], sw.c0));
-                                    xlo = fmin32(xlo, l.x); xhi = fmax32(xhi, l.x);
-                                    ylo = fmin32(ylo, l.y); yhi = fmax32(yhi, l.y);
-                                }
-                            }
-                            lb0 = fmax32(lb0, fmax32(fmax32(xlo - hx, -xhi - hx), fmax32(ylo - hy, -yhi - hy)));
-                        }
-                        float maxDisp = vlen(vsub(sw.c, sw.c0)) + coreR * fabs32(sw.a - sw.a0);
-                        farApart = lb0 - maxDisp > need + 0.002f;
-                    }
-                }
+                const bool farApart = toi_far_apart(pA, pB, sw, shape, hx, hy, coreR);
                 if (farApart) {
                     alpha = 1.0f;
                 } else {

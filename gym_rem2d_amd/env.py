@@ -12,11 +12,13 @@ returns ``reward[N]`` / ``done[N]`` torch tensors.  Rendering (pyglet, ``:655-76
 scope.
 """
 import copy
+import ctypes as C
+import os
 
 import numpy as np
 import torch
 
-from . import gymshim
+from . import _lib, gymshim
 from .compiler import Morphology, build_creature, lanes_for
 from .terrain import make_terrain
 from .world import BatchedWorld
@@ -62,6 +64,8 @@ class BatchedModular2D:
         self.trees = None
         self.robots = None
         self._reward = self._done = None
+        # REM2D_MERGED_LAUNCH=0: step every lane bucket on its own stream instead of one merged grid
+        self.merged_launch = os.environ.get("REM2D_MERGED_LAUNCH", "1") != "0"
 
     def seed(self, seed=None):
         self._seed = seed
@@ -144,6 +148,12 @@ class BatchedModular2D:
     def step(self, n_steps=1):
         if len(self.worlds) == 1:
             self.worlds[0][0].step(n_steps)
+        elif self.merged_launch and len(self.worlds) <= _lib.MAX_WORLDS_PER_STEP:
+            # all lane buckets in one grid per kernel (rem2d_worlds_step): the dispatcher packs the small
+            # buckets next to the big one; on separate streams they mostly ran one after the other
+            w0 = self.worlds[0][0]
+            handles = (C.c_void_p * len(self.worlds))(*[w.h for w, _ in self.worlds])
+            _lib.check(_lib.lib().rem2d_worlds_step(handles, len(self.worlds), int(n_steps), w0._stream()))
         else:
             cur = torch.cuda.current_stream(self.worlds[0][0].device)
             for (w, _), st in zip(self.worlds, self.streams):

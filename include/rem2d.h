@@ -137,6 +137,17 @@ int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream);
 int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                         void *stream);
 
+/* n_steps x Modular2D.step for SEVERAL worlds of one device in one launch per kernel: the lane buckets
+ * (2/4/8/../64 lanes per creature) of one population, which the reference steps as independent envs
+ * (REM2D_main.py:256-267 pool.map over individuals).  Same result as calling rem2d_world_step on each
+ * world; the merged grid lets the GPU pack the small buckets next to the big one instead of running
+ * them one after the other.  All worlds must share the device and the REM2D_FLAG_CONTINUOUS setting;
+ * at most REM2D_MAX_WORLDS_PER_STEP worlds.  Kernel timing is booked on worlds[0]. */
+#define REM2D_MAX_WORLDS_PER_STEP 8
+int rem2d_worlds_step(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, void *stream);
+int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
+                         int32_t pos_iters, void *stream);
+
 /* In-place view of a state field: byte offset into `state`, element count, REM2D_DT_*.
  * Replaces the per-object reads body.position / body.angle / joint.angle and the per-step
  * return values reward / done. */

@@ -77,3 +77,28 @@ def test_evaluate_and_population(need_gpu, oracle, rough_terrain):
     fit = evaluate_population(inds)
     assert fit == ref.tolist()
     assert evaluate(inds[3]) == ref[3]
+
+
+def test_merged_launch_equals_per_bucket_streams(need_gpu):
+    """rem2d_worlds_step (all lane buckets in one grid) vs one rem2d_world_step per bucket: identical state."""
+    import torch
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(96), mutate_odd=True)
+    outs = []
+    for merged in (True, False):
+        env = BatchedModular2D(seed=4)
+        env.merged_launch = merged
+        env.reset_specs(specs)
+        assert len(env.worlds) >= 3  # several lane buckets
+        for n in (1, 3, 60, 120):
+            env.step(n)
+        torch.cuda.synchronize()
+        outs.append(([w.bodies() for w, _ in env.worlds], env.fitness.cpu().numpy().copy(),
+                     [w.view("cn0").cpu().numpy().copy() for w, _ in env.worlds], int(env.errors().max())))
+        env.close()
+    (b0, f0, c0, e0), (b1, f1, c1, e1) = outs
+    assert e0 == 0 and e1 == 0
+    assert all(np.array_equal(x, y) for x, y in zip(b0, b1))
+    assert all(np.array_equal(x, y) for x, y in zip(c0, c1))
+    assert np.array_equal(f0, f1)
