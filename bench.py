@@ -133,11 +133,15 @@ def main():
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-groups", type=int, default=None,
+                    help="independent halves/thirds of the population stepped on separate streams (default: automatic)")
     ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1],
                     help="0 = fused rem2d_step_kernel, 1 = split pre/vel/post pipeline (default: the library's default)")
     ap.add_argument("--discrete", action="store_true",
                     help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
     args = ap.parse_args()
+    if args.step_groups is not None:
+        os.environ["REM2D_STEP_GROUPS"] = str(args.step_groups)
     if args.pipeline is not None:
         os.environ["REM2D_PIPELINE"] = str(args.pipeline)  # read once by librem2d at the first step
 
@@ -223,32 +227,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel: the merged step kernel over all lane buckets (its time is booked on the
-    # first world), or the lane bucket with the most device time when every bucket is launched on its own
-    kern = []
-    for (w, _), m in zip(env.worlds, morphs):
+    # roofline of the dominant kernel.  Default: the merged step kernel (all lane buckets of a step group in one
+    # grid, its time booked on the group's first world); per-bucket launches: the bucket with the most device time.
+    times = []
+    for w, _ in env.worlds:
         ms, launches = w.kernel_time_ms()
         w.enable_timing(False)
-        kern.append((ms, launches, m))
+        times.append((ms, launches, w))
     merged = len(env.worlds) > 1 and env.merged_launch
-    if merged:
-        ms, launches = kern[0][0], kern[0][1]
+    n_groups = max(1, len(env.groups))
+    if merged or len(env.worlds) == 1:
+        ms = sum(t[0] for t in times)
+        launches = sum(t[1] for t in times)       # every launch covers 1/n_groups of the population
         bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
         flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))
-        kname = "rem2d_step_multi_kernel"
+        if max(len(g) for g in env.groups) > 1:
+            kname = "rem2d_step_multi_kernel"
+        else:
+            kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % morphs[0].lanes
     else:
-        ms, launches, m = max(kern, key=lambda k: k[0])
+        ms, launches, wmax = max(times, key=lambda k: k[0])
+        m = morphs[[w for w, _ in env.worlds].index(wmax)]
         bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
         flops_per_step = float(valu_flops_per_env_step(m.n_bodies).sum())
         kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % m.lanes
-    steps_per_launch_avg = args.steps / max(1, launches)
+    # algorithmic bytes of one launch / its average duration == bytes of all timed launches / their total duration
     avg_ms = ms / max(1, launches)
-    achieved = bytes_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    err = int(env.errors().max())
+    achieved = bytes_per_step * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    valu = flops_per_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic_bytes, traffic_src = (pmc_traffic(kname) if (args.workload == "lsystem" and not args.discrete and n_envs == 65536)
                                   else (None, None))
     traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
-    valu = flops_per_step * steps_per_launch_avg / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    err = int(env.errors().max())
 
     if rank == 0:
         out = {
@@ -269,6 +279,7 @@ def main():
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,
                        "continuous_physics": not args.discrete,
                        "parallelism": "population sharded over %d GPU(s), no per-step collective" % world,
+                       "merged_launch": bool(merged), "step_groups": n_groups,
                        "solver_errors": err},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,

@@ -1,7 +1,8 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for ml in 1 0; do
-REM2D_MERGED_LAUNCH=$ml python bench.py --no-cpu-baseline --steps 60 --pipeline 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lsystem fused merged=$ml', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3))"
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for g in 1 2 3; do
+REM2D_STEP_GROUPS=$g python bench.py --no-cpu-baseline --steps 100 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lsystem groups=$g', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3), d['roofline']['launches'], round(d['roofline']['frac'],5))"
 done
-REM2D_WAVES_PER_SIMD=2 python bench.py --no-cpu-baseline --steps 60 --pipeline 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lsystem fused merged W=2', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3))"
-python bench.py --no-cpu-baseline --steps 60 --pipeline 0 --discrete 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('discrete fused merged', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3))"
-python bench.py --no-cpu-baseline --steps 60 --pipeline 0 --workload cppn_hardcore 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('cppn fused merged', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3))"
+for wl in chain8 cppn_hardcore chain4; do
+for g in 1 2; do
+REM2D_STEP_GROUPS=$g python bench.py --no-cpu-baseline --steps 100 --workload $wl 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl groups=$g', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['avg_launch_ms'],3))"
+done; done
