@@ -446,7 +446,27 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     // the merged kernel's 3-waves/SIMD build spills in every lane-count variant; 2 waves/SIMD measured faster
     static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
     const bool three = forced == 3;
-    const int launches = continuous ? n_steps : 1;
+    static const bool split = getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 1;
+    if (split) A.nSteps = 1;
+    VelBatch VB;
+    memset(&VB, 0, sizeof(VB));
+    unsigned vblocks = 0;
+    for (int i = 0; i < n_worlds; ++i) {
+        VB.S[i] = ws[i]->S;
+        VB.lanes[i] = ws[i]->cfg.lanes;
+        vblocks += ((unsigned)ws[i]->L.Lp + VEL_THREADS - 1) / VEL_THREADS;
+        VB.blockEnd[i] = vblocks;
+    }
+    VB.n = n_worlds;
+    VelArgs V;
+    V.K = 0;
+    V.velIters = vel_iters;
+    V.dt = dt;
+    V.friction = w0->T.friction;
+    for (int i = 1; i < n_worlds; ++i)
+        if (split && ws[i]->T.friction != w0->T.friction)
+            return fail(REM2D_E_INVALID, "worlds of one launch must share the terrain friction");
+    const int launches = (continuous || split) ? n_steps : 1;
     for (int l = 0; l < launches; ++l) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (w0->timing) {
@@ -454,8 +474,15 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
             HIP_TRY(hipEventCreate(&e1));
             HIP_TRY(hipEventRecord(e0, st));
         }
-        if (three) hipLaunchKernelGGL(rem2d_step_multi_kernel<3>, grid, block, 0, st, B, A);
-        else hipLaunchKernelGGL(rem2d_step_multi_kernel<2>, grid, block, 0, st, B, A);
+        if (split) {
+            hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
+            hipLaunchKernelGGL(rem2d_vel_multi_kernel, dim3(vblocks), dim3(VEL_THREADS), 0, st, VB, V);
+            hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
+        } else if (three) {
+            hipLaunchKernelGGL(rem2d_step_multi_kernel<3>, grid, block, 0, st, B, A);
+        } else {
+            hipLaunchKernelGGL(rem2d_step_multi_kernel<2>, grid, block, 0, st, B, A);
+        }
         if (w0->timing) {
             HIP_TRY(hipEventRecord(e1, st));
             w0->pending.emplace_back(e0, e1);

@@ -34,9 +34,9 @@ struct VelArgs { int K; int velIters; float dt; float friction; };
 // pre: Modular2D.step's controller sweep, b2World::Step up to (not including) the warm start
 // ---------------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_pre_kernel(State S, Terrain T, StepArgs A) {
+DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
     const int lane = threadIdx.x;
-    const unsigned gl = blockIdx.x * WAVE + lane;
+    const unsigned gl = block * WAVE + lane;
     const unsigned env = gl / K;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
@@ -190,6 +190,16 @@ __global__ __launch_bounds__(WAVE) void rem2d_pre_kernel(State S, Terrain T, Ste
     }
 }
 
+template <int K>
+__global__ __launch_bounds__(WAVE) void rem2d_pre_kernel(State S, Terrain T, StepArgs A) {
+    pre_body<K>(S, T, A, blockIdx.x);
+}
+__global__ __launch_bounds__(WAVE) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(pre_body)
+}
+
 // ---------------------------------------------------------------------------------------------------
 // vel: warm start + velocity iterations + StoreImpulses, lanes = constraints
 // ---------------------------------------------------------------------------------------------------
@@ -265,16 +275,23 @@ DEV int wave_or(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_kernel(State S, VelArgs A) {
-    __shared__ float vel[3][VEL_THREADS];            // body velocity mailbox (vx, vy, w)
-    __shared__ int cntJ[VEL_PHASES][VEL_WAVES];      // joints per (phase, wave)
-    __shared__ int cntC[VEL_WAVES];                  // touching bodies per wave
-    __shared__ int redA[VEL_WAVES], redB[VEL_WAVES], redC[VEL_WAVES], redD[VEL_WAVES];
-    __shared__ unsigned char jlist[VEL_THREADS];     // joint lane -> child body (workgroup-local id)
-    __shared__ unsigned char clist[VEL_THREADS];     // contact lane -> body
+struct VelShared {
+    float vel[3][VEL_THREADS];            // body velocity mailbox (vx, vy, w)
+    int cntJ[VEL_PHASES][VEL_WAVES];      // joints per (phase, wave)
+    int cntC[VEL_WAVES];                  // touching bodies per wave
+    int redA[VEL_WAVES], redB[VEL_WAVES], redC[VEL_WAVES], redD[VEL_WAVES];
+    unsigned char jlist[VEL_THREADS];     // joint lane -> child body (workgroup-local id)
+    unsigned char clist[VEL_THREADS];     // contact lane -> body
+};
+DEV void vel_body(const State &S, const VelArgs &A, unsigned block, VelShared &sh) {
+    float (&vel)[3][VEL_THREADS] = sh.vel;
+    int (&cntJ)[VEL_PHASES][VEL_WAVES] = sh.cntJ;
+    int (&cntC)[VEL_WAVES] = sh.cntC;
+    int (&redA)[VEL_WAVES] = sh.redA, (&redB)[VEL_WAVES] = sh.redB, (&redC)[VEL_WAVES] = sh.redC, (&redD)[VEL_WAVES] = sh.redD;
+    unsigned char (&jlist)[VEL_THREADS] = sh.jlist, (&clist)[VEL_THREADS] = sh.clist;
 
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & (WAVE - 1);
-    const unsigned wg0 = blockIdx.x * VEL_THREADS;
+    const unsigned wg0 = block * VEL_THREADS;
     const unsigned Lp = S.Lp;
     const int K = A.K;
     const int iters = A.velIters;
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_kernel(State S, VelArgs
     // ---------------- contact role: lane VEL_THREADS-1-i solves the contacts of body clist[i] ----------------
     // contact lanes fill one wavefront from the top; which wavefront rotates with the workgroup so that the
     // contact work of the workgroups resident on one CU does not pile up on the same SIMD
-    const int crot = (int)((blockIdx.x >> 8) + (blockIdx.x >> 10)) & (VEL_WAVES - 1);
+    const int crot = (int)((block >> 8) + (block >> 10)) & (VEL_WAVES - 1);
     const int ci = VEL_THREADS - 1 - ((tid + crot * WAVE) & (VEL_THREADS - 1));
     const bool crole = ci < NC;
     ContactC cc[KR];
@@ -533,14 +550,35 @@ __global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_kernel(State S, VelArgs
     }
 }
 
+__global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_kernel(State S, VelArgs A) {
+    __shared__ VelShared sh;
+    vel_body(S, A, blockIdx.x, sh);
+}
+// several worlds in one launch: blockEnd counts VEL_THREADS-wide blocks here
+struct VelBatch {
+    State S[REM2D_MAX_BATCH];
+    unsigned blockEnd[REM2D_MAX_BATCH];
+    int lanes[REM2D_MAX_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(VEL_THREADS) void rem2d_vel_multi_kernel(VelBatch B, VelArgs A) {
+    __shared__ VelShared sh;
+    unsigned block = blockIdx.x;
+    int b = 0;
+    while (b + 1 < B.n && block >= B.blockEnd[b]) ++b;
+    if (b > 0) block -= B.blockEnd[b - 1];
+    VelArgs Ab = A;
+    Ab.K = B.lanes[b];
+    vel_body(B.S[b], Ab, block, sh);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // post: position integration / iterations, sleep, broadphase refresh, bookkeeping
 // ---------------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_post_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ PosShared psh;
+DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
     const int lane = threadIdx.x;
-    const unsigned gl = blockIdx.x * WAVE + lane;
+    const unsigned gl = block * WAVE + lane;
     const unsigned env = gl / K;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
@@ -657,6 +695,18 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_kernel(State S, Terrain T, St
         EI(E_POSITERS) = lastPosIters;
     }
     if (!A.defer) env_bookkeeping(S, env, sub, __shfl(px, base));
+}
+
+template <int K>
+__global__ __launch_bounds__(WAVE) void rem2d_post_kernel(State S, Terrain T, StepArgs A) {
+    __shared__ PosShared psh;
+    post_body<K>(S, T, A, blockIdx.x, psh);
+}
+__global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArgs A) {
+    __shared__ PosShared psh;
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(post_body, psh)
 }
 
 #endif

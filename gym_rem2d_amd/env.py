@@ -121,11 +121,15 @@ class BatchedModular2D:
         # wavefronts.  Two independent halves of the population on two streams let one half's TOI tail run
         # under the other half's step kernel.  (Creatures are independent, so any split is legal.)
         # The tail grows with the bodies per creature and is short for small uniform creatures (measured:
-        # 65 536 8-module chains lose 5 % with two groups, mixed L-system / 32-lane populations gain 25-30 %).
+        # 65 536 8-module chains lose 5 % with two groups, mixed L-system / 32-lane populations gain 30-40 % with two or three).
         groups = self.step_groups
         if groups <= 0:
             big = len(batches) > 1 or max(m.lanes for m, _ in batches) >= 16
-            groups = 2 if (self.flags & _lib.FLAG_CONTINUOUS) and n_envs >= 32768 and big else 1
+            # three at most: with the caller's stream that makes four, the number of hardware queues HIP maps
+            # streams onto by default -- a fourth group stream was measured to serialise (20 M instead of 29 M)
+            groups = 1
+            if (self.flags & _lib.FLAG_CONTINUOUS) and big:
+                groups = 3 if n_envs >= 49152 else (2 if n_envs >= 32768 else 1)
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
