@@ -47,15 +47,15 @@ def valu_flops_per_env_step(n_bodies, vel_iters=180):
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_d_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command)."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    (profiles/r01_e_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command)."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
         # profile keys carry both template arguments ("rem2d_step_kernel<16, 3>"); match on <K
         stem = kernel_name.rstrip(">")
         for k, v in d["kernels"].items():
-            if k == kernel_name or k.startswith(stem + ","):
+            if k == kernel_name or k.startswith(stem + ",") or k.startswith(kernel_name + "<"):
                 return float(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
         return None, None
     except Exception:  # noqa: BLE001
@@ -251,6 +251,7 @@ def main():
         bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
         flops_per_step = float(valu_flops_per_env_step(m.n_bodies).sum())
         kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % m.lanes
+    bytes_per_step_all = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
     # algorithmic bytes of one launch / its average duration == bytes of all timed launches / their total duration
     avg_ms = ms / max(1, launches)
     achieved = bytes_per_step * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -284,6 +285,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "avg_launch_ms": avg_ms, "launches": launches,
+                         # launches of different step groups overlap on the chip, which stretches every launch;
+                         # the same bytes over the wall time of the timed region:
+                         "achieved_wall": bytes_per_step_all * args.steps / dt / 1e9,
+                         "frac_wall": bytes_per_step_all * args.steps / dt / 1e9 / 8000.0,
                          "valu_tflops_est": valu, "valu_frac_of_157.3": valu / 157.3,
                          "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d); "
                                  "the path is FP32-VALU/latency bound, not HBM bound"},
