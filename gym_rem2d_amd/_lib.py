@@ -101,6 +101,7 @@ def lib():
     L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
     L.rem2d_worlds_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_void_p]
+    L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]

@@ -72,6 +72,7 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_position.h"
 #include "rem2d_kernels.h"
 #include "rem2d_pipeline.h"
+#include "rem2d_diversity.h"
 
 // =====================================================================================
 // host side: handle + C ABI
@@ -501,6 +502,19 @@ extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32
 extern "C" int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream) {
     // Modular2DEnv.py:634  self.world.Step(1.0/FPS, 6*30, 2*30)
     return rem2d_world_step_ex(w, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream);
+}
+
+extern "C" int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_dev, int32_t n_trees, int32_t max_nodes,
+                                    int64_t *out_dev, int32_t device, void *stream) {
+    if (!pos_dev || !count_dev || !out_dev) return fail(REM2D_E_INVALID, "NULL device pointer");
+    if (n_trees < 0 || max_nodes <= 0 || max_nodes > DIV_MAX_NODES)
+        return fail(REM2D_E_INVALID, "max_nodes must be 1..64");
+    if (n_trees == 0) return REM2D_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(rem2d_tree_diversity_kernel, dim3((unsigned)n_trees), dim3(DIV_THREADS), 0, (hipStream_t)stream, pos_dev,
+                       count_dev, n_trees, max_nodes, (long long *)out_dev);
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
 }
 
 extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {

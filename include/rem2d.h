@@ -148,6 +148,15 @@ int rem2d_worlds_step(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_st
 int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                          int32_t pos_iters, void *stream);
 
+/* Population diversity (DataAnalysis/AdvancedDataAnalysis.py:291-313 compare_distance, :367-381
+ * tree_edit_distance): out[c] = sum over t != c of the number of nodes of c whose (x, y) position does not
+ * occur in t plus the number of nodes of t that no node of c sits on; positions are binary64 and compared
+ * with ==.  pos_dev [n_trees][max_nodes][2] f64 (get_tree_pos layout, computed by the caller),
+ * count_dev [n_trees] i32 (nodes per tree, <= max_nodes <= 64), out_dev [n_trees] i64.  Device pointers;
+ * asynchronous on `stream`.  Independent of any rem2d_world. */
+int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_dev, int32_t n_trees, int32_t max_nodes,
+                         int64_t *out_dev, int32_t device, void *stream);
+
 /* In-place view of a state field: byte offset into `state`, element count, REM2D_DT_*.
  * Replaces the per-object reads body.position / body.angle / joint.angle and the per-step
  * return values reward / done. */

@@ -324,6 +324,34 @@ def main():
         chains[site] = dict(tree=dump_tree(tree), layout=dump_layout(env))
     with open(os.path.join(OUT, "layout_chain.json"), "w") as f:
         json.dump(chains, f)
+
+    # ---- diversity metric (DataAnalysis/AdvancedDataAnalysis.py:291-381) on seeded populations
+    spec = importlib.util.spec_from_file_location("ref_advanced_data_analysis",
+                                                  os.path.join(REF, "DataAnalysis", "AdvancedDataAnalysis.py"))
+    ADA = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ADA)
+
+    class _Ind:
+        tree_depth = 8
+
+        def __init__(self, genome):
+            self.genome = genome
+
+    div = {}
+    for enc, n_seeds in (("lsystem", 32), ("direct", 24)):
+        pop = []
+        for seed in range(n_seeds):
+            random.seed(seed)
+            ml = module_list()
+            genome = de.DirectEncoding(ml) if enc == "direct" else ls.LSystem(ml)
+            if enc == "lsystem" and seed % 2 == 1:
+                for _ in range(3):
+                    genome.mutate(0.5, 0.5, 0.5)
+            pop.append(_Ind(genome))
+        positions = [[[float(v.pos[0]), float(v.pos[1])] for v in ADA.get_tree_pos(ind.genome.create(8))] for ind in pop]
+        div[enc] = dict(n=n_seeds, positions=positions, diversity=[float(v) for v in ADA.tree_edit_distance(pop)])
+    with open(os.path.join(OUT, "diversity.json"), "w") as f:
+        json.dump(div, f)
     print("wrote fixtures to", os.path.normpath(OUT))
 
 
