@@ -47,6 +47,13 @@ class Morph(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in MORPH_FIELDS]
 
 
+class LsystemGenomes(C.Structure):
+    """rem2d_lsystem_genomes (include/rem2d.h): host pointers, SoA over genomes."""
+    _fields_ = [("n", C.c_int32), ("n_types", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "mod_shape", "mod_width", "mod_height", "mod_radius", "mod_angle", "mod_torque", "ctl_amp", "ctl_phase",
+        "ctl_freq", "ctl_offset", "rule_n", "rule_site", "rule_ref")]
+
+
 class Rem2dError(RuntimeError):
     pass
 
@@ -101,6 +108,8 @@ def lib():
     L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
     L.rem2d_worlds_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_void_p]
+    L.rem2d_compile_lsystem.argtypes = [C.POINTER(LsystemGenomes), C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                        C.POINTER(Morph), C.c_void_p, C.c_int32]
     L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]

@@ -517,6 +517,8 @@ extern "C" int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_
     return REM2D_OK;
 }
 
+#include "rem2d_compile.h"
+
 extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
     if (!w || field < 0 || field >= REM2D_F_COUNT) return fail(REM2D_E_INVALID, "bad field id");
     int dt = 0;

@@ -1,0 +1,346 @@
+// rem2d_compile.h -- host-side genotype -> phenotype -> SoA morphology for L-system genomes, native and
+// multi-threaded.  Part of the single translation unit rem2d.hip; host code only.
+//
+// Restates, in binary64 with the same libm calls in the same order, what the Python layer does per
+// individual and what is pinned bit-for-bit against the reference's fixtures there:
+//   LSystem.create          Encodings/LSystem.py:144-199   (gym_rem2d_amd/encodings/lsystem.py)
+//   create_robot            Modular2DEnv.py:517-563        (compiler.build_creature)
+//   Standard2D / Circular2D simple_module.py:147-199,231-313, circular_module.py:138-221 (modules.py)
+//   create_joint            module_utility.py:7-33         (modules._site_to_anchor_frame)
+//   island order, joint rounds, modulo schedule            (compiler.island_joint_order / joint_rounds /
+//                                                           pipeline_schedule)
+// and writes the [creature][lane] arrays rem2d_world_reset uploads.  tests/test_compile_native.py compares
+// every output word with the Python path over thousands of seeded genomes.
+#ifndef REM2D_COMPILE_H
+#define REM2D_COMPILE_H
+
+#include <thread>
+
+namespace rem2d_host {
+
+static const int MAXN = 64;     // nodes / bodies per creature
+static const double PI = 3.141592653589793; // math.pi
+
+static inline double f32r(double v) { return (double)(float)v; } // the SWIG boundary: python double -> float32 -> double
+
+struct TreeNode { int index, parent, type, site; }; // site: -1 none, 0 left, 1 right, 2 top
+
+struct Genome {
+    int nTypes;
+    const int32_t *shape;
+    const double *width, *height, *radius, *angle, *torque, *amp, *phase, *freq, *offset;
+    const int32_t *ruleN, *ruleSite, *ruleRef;
+};
+
+// ---- LSystem.create ----
+struct Sym { int index, parent, ref, site; bool handled; int nChild; int child[3]; };
+struct Expander {
+    const Genome &g;
+    int maxModules;
+    Sym pool[4 * MAXN];
+    int nPool;
+    bool overflow;
+    Expander(const Genome &gg, int mm) : g(gg), maxModules(mm), nPool(0), overflow(false) {}
+    int rewrite(int s, int index) {
+        if (index > maxModules) return index;
+        Sym &sym = pool[s];
+        if (!sym.handled) {
+            sym.handled = true;
+            const int r = sym.ref;
+            for (int c = 0; c < g.ruleN[r]; ++c) { // Rule.update
+                index += 1;
+                if (nPool >= 4 * MAXN) { overflow = true; return index; }
+                Sym &f = pool[nPool];
+                f.index = index; f.parent = pool[s].index; f.ref = g.ruleRef[r * 3 + c]; f.site = g.ruleSite[r * 3 + c];
+                f.handled = false; f.nChild = 0;
+                pool[s].child[pool[s].nChild++] = nPool++;
+            }
+        } else {
+            for (int c = 0; c < sym.nChild; ++c) index = rewrite(pool[s].child[c], index);
+        }
+        return index;
+    }
+    int emit(int parentIndex, int s, TreeNode *nodes, int &nNodes, int counter) {
+        if (counter > maxModules) return counter;
+        if (nNodes >= MAXN) { overflow = true; return counter; }
+        nodes[nNodes].index = pool[s].index; nodes[nNodes].parent = parentIndex;
+        nodes[nNodes].type = pool[s].ref; nodes[nNodes].site = pool[s].site;
+        ++nNodes;
+        for (int c = 0; c < pool[s].nChild; ++c) {
+            counter += 1;
+            counter = emit(pool[pool[s].child[c]].parent, pool[s].child[c], nodes, nNodes, counter);
+        }
+        return counter;
+    }
+    int create(int treeDepth, TreeNode *nodes) {
+        nPool = 1;
+        pool[0].index = 0; pool[0].parent = -1; pool[0].ref = 0; pool[0].site = -1; pool[0].handled = false; pool[0].nChild = 0;
+        int index = 0;
+        for (int d = 0; d < treeDepth; ++d) index = rewrite(0, index);
+        int nNodes = 0;
+        emit(-1, 0, nodes, nNodes, 0);
+        return nNodes;
+    }
+};
+
+// ---- create_robot ----
+struct Body { int shape; double hx, hy, x, y, angle; }; // values already rounded to binary32
+struct Joint { int parent, child; double ax, ay, bx, by, torque; int node; };
+struct Creature { int nBodies, nJoints; Body bodies[MAXN]; Joint joints[MAXN]; bool overflow; };
+
+static inline double site_value(int site) { return site == 0 ? -1.0 : (site == 1 ? 1.0 : 0.0); }
+
+static void connection_site(const Genome &g, int ptype, int site, const Body &pb, double &sx, double &sy, double &sth) {
+    const double con = site_value(site);
+    if (g.shape[ptype] == 1) { // Standard2D.get_global_position_of_connection_site
+        const double height = g.height[ptype], width = g.width[ptype];
+        double ray = con * g.angle[ptype] + PI / 2;
+        while (ray > 2 * PI) ray -= 2 * PI;
+        const double flip_x = (0.5 * PI < ray && ray < 1.5 * PI) ? -1.0 : 1.0;
+        const double flip_y = (PI < ray && ray < 2 * PI) ? -1.0 : 1.0;
+        const double s = sin(ray), c = cos(ray);
+        double tb0, tb1, lr0, lr1;
+        if (2 * s == 0) { tb0 = 10000; tb1 = 10000; }
+        else { tb0 = (height * c) / (2 * s) * flip_y; tb1 = height / 2 * flip_y; }
+        if (2 * c == 0) { lr0 = 10000; lr1 = 10000; }
+        else { lr0 = width / 2 * flip_x; lr1 = (width * s) / (2 * c) * flip_x; }
+        const double d_tb = sqrt(pow(tb0, 2) + pow(tb1, 2));
+        const double d_lr = sqrt(pow(lr0, 2) + pow(lr1, 2));
+        const double reach = d_lr < d_tb ? d_lr : d_tb;
+        const double pangle = pb.angle;
+        sx = (cos(pangle + ray) * reach) + pb.x;
+        sy = (sin(pangle + ray) * reach) + pb.y;
+        sth = pangle + ray - PI / 2;
+    } else { // Circular2D
+        double turn = con * g.angle[ptype];
+        turn += pb.angle;
+        const double r0 = cos(turn + PI / 2) * g.radius[ptype], r1 = sin(turn + PI / 2) * g.radius[ptype];
+        sx = r0 + pb.x; sy = r1 + pb.y; sth = turn;
+    }
+}
+
+static void build_creature(const Genome &g, const TreeNode *nodes, int nNodes, double terrainHeight, Creature &cr) {
+    cr.nBodies = cr.nJoints = 0;
+    cr.overflow = false;
+    bool expressed[MAXN];
+    int component[MAXN]; // body slot or -1
+    int handled[MAXN], nHandled = 0;
+    for (int i = 0; i < nNodes; ++i) { expressed[i] = false; component[i] = -1; }
+    auto emit = [&](int ni, int parentBody, bool haveSite, double sx, double sy, double sth) {
+        const int t = nodes[ni].type;
+        double pos0 = 5, pos1 = terrainHeight + 2; // SPAWN (Modular2DEnv.py:429-432)
+        double angle = 0;
+        expressed[ni] = true;
+        int shape; double hx, hy;
+        if (g.shape[t] == 1) {
+            const double n_height = g.height[t], n_width = g.width[t];
+            if (parentBody >= 0) {
+                const double up = sth + angle + PI / 2;
+                pos0 = (cos(up) * n_height / 2) + sx;
+                pos1 = (sin(up) * n_height / 2) + sy;
+            }
+            if (pos1 - sqrt(pow(n_width, 2) + pow(n_height, 2)) < terrainHeight) return;
+            if (haveSite) angle += sth;
+            shape = 1; hx = n_width / 2; hy = n_height / 2;
+        } else {
+            const double r = g.radius[t];
+            if (parentBody >= 0) {
+                const double up = sth + PI / 2;
+                pos0 = (cos(up) * r) + sx;
+                pos1 = (sin(up) * r) + sy;
+            }
+            if (haveSite) angle += sth;
+            if (pos1 - r < terrainHeight) return;
+            shape = 2; hx = r; hy = 0.0;
+        }
+        if (cr.nBodies >= MAXN) { cr.overflow = true; return; }
+        const int slot = cr.nBodies++;
+        Body &b = cr.bodies[slot];
+        b.shape = shape; b.hx = f32r(hx); b.hy = f32r(hy); b.x = f32r(pos0); b.y = f32r(pos1); b.angle = f32r(angle);
+        component[ni] = slot;
+        if (haveSite) { // module_utility.create_joint
+            const Body &pa = cr.bodies[parentBody];
+            const double dis_a = sqrt(pow(sx - pa.x, 2) + pow(sy - pa.y, 2));
+            const double ang_a = sth - pa.angle + PI / 2;
+            const double dis_b = sqrt(pow(sx - b.x, 2) + pow(sy - b.y, 2));
+            const double ang_b = b.angle - sth - PI / 2;
+            Joint &j = cr.joints[cr.nJoints++];
+            j.parent = parentBody; j.child = slot;
+            j.ax = f32r(cos(ang_a) * dis_a); j.ay = f32r(sin(ang_a) * dis_a);
+            j.bx = f32r(cos(ang_b) * dis_b); j.by = f32r(sin(ang_b) * dis_b);
+            j.torque = f32r(g.torque[t]);
+            j.node = ni;
+        }
+    };
+    for (int i = 0; i < nNodes; ++i)
+        if (nodes[i].parent == -1) { emit(i, -1, false, 0, 0, 0); handled[nHandled++] = i; }
+    for (int i = 0; i < nNodes; ++i) {
+        if (expressed[i]) continue;
+        int p = -1;
+        for (int h = 0; h < nHandled; ++h)
+            if (nodes[handled[h]].index == nodes[i].parent && expressed[handled[h]]) { p = handled[h]; break; }
+        if (p < 0 || component[p] < 0) continue;
+        double sx, sy, sth;
+        connection_site(g, nodes[p].type, nodes[i].site, cr.bodies[component[p]], sx, sy, sth);
+        emit(i, component[p], true, sx, sy, sth);
+        handled[nHandled++] = i;
+    }
+}
+
+// ---- island order, rounds, modulo schedule ----
+static void schedule(const Creature &cr, int *rounds, int *offC, int &period) {
+    const int nb = cr.nBodies, nj = cr.nJoints;
+    // joint edges head-inserted per body
+    int edges[MAXN][MAXN], nEdges[MAXN];
+    for (int b = 0; b < nb; ++b) nEdges[b] = 0;
+    for (int k = 0; k < nj; ++k) {
+        const int ab[2] = {cr.joints[k].parent, cr.joints[k].child};
+        for (int e = 0; e < 2; ++e) {
+            const int b = ab[e];
+            for (int i = nEdges[b]; i > 0; --i) edges[b][i] = edges[b][i - 1];
+            edges[b][0] = k;
+            ++nEdges[b];
+        }
+    }
+    int order[MAXN], nOrder = 0, stack[MAXN];
+    bool jflag[MAXN], bflag[MAXN];
+    for (int k = 0; k < nj; ++k) jflag[k] = false;
+    for (int b = 0; b < nb; ++b) bflag[b] = false;
+    for (int seed = nb - 1; seed >= 0; --seed) {
+        if (bflag[seed]) continue;
+        int sp = 0;
+        stack[sp++] = seed;
+        bflag[seed] = true;
+        while (sp > 0) {
+            const int b = stack[--sp];
+            for (int i = 0; i < nEdges[b]; ++i) {
+                const int k = edges[b][i];
+                if (jflag[k]) continue;
+                const int a = cr.joints[k].parent, c = cr.joints[k].child;
+                const int other = a == b ? c : a;
+                order[nOrder++] = k;
+                jflag[k] = true;
+                if (bflag[other]) continue;
+                stack[sp++] = other;
+                bflag[other] = true;
+            }
+        }
+    }
+    int last[MAXN], first[MAXN], lastTouch[MAXN];
+    for (int b = 0; b < nb; ++b) { lastTouch[b] = -1; last[b] = 0; first[b] = -1; }
+    for (int o = 0; o < nOrder; ++o) {
+        const int k = order[o], a = cr.joints[k].parent, b = cr.joints[k].child;
+        const int r = (lastTouch[a] > lastTouch[b] ? lastTouch[a] : lastTouch[b]) + 1;
+        rounds[k] = r;
+        lastTouch[a] = lastTouch[b] = r;
+    }
+    for (int k = 0; k < nj; ++k) {
+        const int ab[2] = {cr.joints[k].parent, cr.joints[k].child};
+        for (int e = 0; e < 2; ++e) {
+            const int x = ab[e];
+            if (rounds[k] > last[x]) last[x] = rounds[k];
+            if (first[x] < 0 || rounds[k] < first[x]) first[x] = rounds[k];
+        }
+    }
+    period = 1;
+    for (int k = 0; k < nj; ++k) {
+        const int a = cr.joints[k].parent, b = cr.joints[k].child;
+        const int p = (last[a] > last[b] ? last[a] : last[b]) + 1 - rounds[k];
+        if (p > period) period = p;
+    }
+    for (int b = 0; b < nb; ++b) {
+        offC[b] = last[b];
+        if (first[b] < 0) continue;
+        int m = (period - 1 - last[b]) % period; // python modulo: non-negative for positive period
+        if (m < 0) m += period;
+        const int v = last[b] + m;
+        if (v <= first[b] + period - 1) offC[b] = v;
+    }
+}
+
+} // namespace rem2d_host
+
+extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tree_depth, int32_t max_modules,
+                                     double terrain_height, int32_t lanes, const rem2d_morph *out, int32_t *n_bodies,
+                                     int32_t n_threads) {
+    using namespace rem2d_host;
+    if (!G || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (G->n_types <= 0 || G->n_types > 64) return fail(REM2D_E_INVALID, "n_types must be 1..64");
+    if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
+    const int n = G->n, T = G->n_types;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads > n) n_threads = n > 0 ? n : 1;
+    const float lower = (float)(-PI / 2), upper = (float)(PI / 2);
+    std::vector<int> status((size_t)(n_threads > 0 ? n_threads : 1), 0);
+    auto work = [&](int tid) {
+        // contiguous blocks per thread: neighbouring creatures share cache lines of the output arrays
+        const int per = (n + n_threads - 1) / n_threads;
+        const int e0 = tid * per, e1 = e0 + per < n ? e0 + per : n;
+        for (int e = e0; e < e1; ++e) {
+            Genome g;
+            g.nTypes = T;
+            g.shape = G->mod_shape + (size_t)e * T;
+            g.width = G->mod_width + (size_t)e * T; g.height = G->mod_height + (size_t)e * T;
+            g.radius = G->mod_radius + (size_t)e * T; g.angle = G->mod_angle + (size_t)e * T;
+            g.torque = G->mod_torque + (size_t)e * T;
+            g.amp = G->ctl_amp + (size_t)e * T; g.phase = G->ctl_phase + (size_t)e * T;
+            g.freq = G->ctl_freq + (size_t)e * T; g.offset = G->ctl_offset + (size_t)e * T;
+            g.ruleN = G->rule_n + (size_t)e * T; g.ruleSite = G->rule_site + (size_t)e * T * 3;
+            g.ruleRef = G->rule_ref + (size_t)e * T * 3;
+            TreeNode nodes[MAXN];
+            Expander ex(g, max_modules);
+            const int nNodes = ex.create(tree_depth, nodes);
+            Creature cr;
+            build_creature(g, nodes, nNodes, terrain_height, cr);
+            if (ex.overflow || cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
+            int rounds[MAXN], offC[MAXN], period;
+            schedule(cr, rounds, offC, period);
+            const size_t lo = (size_t)e * lanes;
+            for (int l = 0; l < lanes; ++l) {
+                const size_t i = lo + l;
+                ((int32_t *)out->shape)[i] = 0; ((int32_t *)out->parent)[i] = -1; ((int32_t *)out->jround)[i] = 0;
+                ((float *)out->hx)[i] = 0; ((float *)out->hy)[i] = 0; ((float *)out->x)[i] = 0; ((float *)out->y)[i] = 0;
+                ((float *)out->angle)[i] = 0; ((float *)out->ax)[i] = 0; ((float *)out->ay)[i] = 0;
+                ((float *)out->bx)[i] = 0; ((float *)out->by)[i] = 0; ((float *)out->torque)[i] = 0;
+                ((float *)out->lower)[i] = 0; ((float *)out->upper)[i] = 0;
+                ((double *)out->amp)[i] = 0; ((double *)out->phase)[i] = 0; ((double *)out->freq)[i] = 0;
+                ((double *)out->offset)[i] = 0; ((double *)out->istate)[i] = 0;
+            }
+            for (int b = 0; b < cr.nBodies; ++b) {
+                const size_t i = lo + b;
+                ((int32_t *)out->jround)[i] = (offC[b] << 8) | (period << 16);
+                ((int32_t *)out->shape)[i] = cr.bodies[b].shape;
+                ((float *)out->hx)[i] = (float)cr.bodies[b].hx; ((float *)out->hy)[i] = (float)cr.bodies[b].hy;
+                ((float *)out->x)[i] = (float)cr.bodies[b].x; ((float *)out->y)[i] = (float)cr.bodies[b].y;
+                ((float *)out->angle)[i] = (float)cr.bodies[b].angle;
+            }
+            for (int k = 0; k < cr.nJoints; ++k) {
+                const Joint &j = cr.joints[k];
+                const size_t i = lo + j.child;
+                const int t = nodes[j.node].type;
+                ((int32_t *)out->parent)[i] = j.parent;
+                ((int32_t *)out->jround)[i] |= rounds[k];
+                ((float *)out->ax)[i] = (float)j.ax; ((float *)out->ay)[i] = (float)j.ay;
+                ((float *)out->bx)[i] = (float)j.bx; ((float *)out->by)[i] = (float)j.by;
+                ((float *)out->torque)[i] = (float)j.torque;
+                ((float *)out->lower)[i] = lower; ((float *)out->upper)[i] = upper;
+                ((double *)out->amp)[i] = g.amp[t]; ((double *)out->phase)[i] = g.phase[t];
+                ((double *)out->freq)[i] = g.freq[t]; ((double *)out->offset)[i] = g.offset[t];
+                ((double *)out->istate)[i] = 0.0;
+            }
+            n_bodies[e] = cr.nBodies;
+        }
+    };
+    if (n_threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    for (int s : status)
+        if (s) return fail(REM2D_E_INVALID, "a creature has more bodies than `lanes` (n_bodies = -1 marks it)");
+    return REM2D_OK;
+}
+
+#endif

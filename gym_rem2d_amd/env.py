@@ -223,6 +223,12 @@ class BatchedModular2D:
         out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
         return self._gather("frozen", out)
 
+    @property
+    def steps(self):
+        """env steps taken since reset, int32 [N]."""
+        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
+        return self._gather("steps", out)
+
     def errors(self):
         out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
         return self._gather("err", out)

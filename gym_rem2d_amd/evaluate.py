@@ -66,14 +66,16 @@ def run_episode(env, max_steps=EPISODE_CAP, chunk=100):
     return env.fitness.clone()
 
 
-def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, **env_kw):
-    """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats."""
+def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, workers=None, **env_kw):
+    """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats.
+    The genotype -> phenotype step runs on ``workers`` host processes (encode.encode_population)."""
+    from .encode import encode_population
     from .env import BatchedModular2D
     own = env is None
     if own:
         env = BatchedModular2D(**env_kw)
-    trees = [ind.genome.create(tree_depth if tree_depth is not None else ind.tree_depth) for ind in individuals]
-    env.reset(trees, [ind.genome.moduleList for ind in individuals])
+    env.trees = env.robots = None
+    env._upload(encode_population(individuals, tree_depth, workers), len(individuals))
     fit = run_episode(env, max_steps).cpu().tolist()
     if own:
         env.close()

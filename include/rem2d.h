@@ -148,6 +148,29 @@ int rem2d_worlds_step(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_st
 int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                          int32_t pos_iters, void *stream);
 
+/* Host-side genotype -> phenotype for L-system genomes (Encodings/LSystem.py:144-199 create, then
+ * Modular2DEnv.py:517-563 create_robot with simple_module.py:147-199,231-313, circular_module.py:138-221 and
+ * module_utility.py:7-33), native and multi-threaded: n genomes in, the [creature][lane] arrays of
+ * rem2d_world_reset out.  HOST pointers throughout.  SoA over genomes; a genome has n_types module
+ * prototypes (the reference: 4 boxes + 4 circles, REM2D_main.py:69-77) and one rewriting rule per type. */
+typedef struct rem2d_lsystem_genomes {
+    int32_t n, n_types;
+    const int32_t *mod_shape;                 /* [n][n_types] 1 box (Standard2D), 2 circle (Circular2D) */
+    const double *mod_width, *mod_height;     /* [n][n_types] box */
+    const double *mod_radius;                 /* [n][n_types] circle */
+    const double *mod_angle, *mod_torque;     /* [n][n_types] */
+    const double *ctl_amp, *ctl_phase, *ctl_freq, *ctl_offset; /* [n][n_types] prototype controller */
+    const int32_t *rule_n;                    /* [n][n_types] products of the rule for that type (0..3) */
+    const int32_t *rule_site;                 /* [n][n_types][3] 0 left, 1 right, 2 top */
+    const int32_t *rule_ref;                  /* [n][n_types][3] module type of the product */
+} rem2d_lsystem_genomes;
+/* out: host arrays of n*lanes elements each (same fields as rem2d_morph, written, not read);
+ * n_bodies[n]: bodies of every creature.  Fails (and marks the creature with n_bodies = -1) if a creature
+ * needs more than `lanes` lanes.  max_modules <= 63.  n_threads <= 0: all hardware threads. */
+int rem2d_compile_lsystem(const rem2d_lsystem_genomes *genomes, int32_t tree_depth, int32_t max_modules,
+                          double terrain_height, int32_t lanes, const rem2d_morph *out, int32_t *n_bodies,
+                          int32_t n_threads);
+
 /* Population diversity (DataAnalysis/AdvancedDataAnalysis.py:291-313 compare_distance, :367-381
  * tree_edit_distance): out[c] = sum over t != c of the number of nodes of c whose (x, y) position does not
  * occur in t plus the number of nodes of t that no node of c sits on; positions are binary64 and compared

@@ -67,3 +67,31 @@ def test_one_generation_on_gpu():
     fits = [p.fitness for p in pop]
     assert len(fits) == 32 and all(np.isfinite(fits)) and max(fits) > 0
     assert hist[-1][2] == max(fits)
+
+
+def test_parallel_encoder_equals_serial_path():
+    """encode_population on a fork pool == the serial compiler path, creature for creature and in the same
+    (lane bucket, pipeline period, rounds, bodies) order as BatchedModular2D.reset_specs."""
+    import random
+    import numpy as np
+    from gym_rem2d_amd import Morphology, build_creature
+    from gym_rem2d_amd.compiler import lanes_for
+    from gym_rem2d_amd.ea import Individual
+    import gym_rem2d_amd.encode as E
+    random.seed(5)
+    inds = [Individual.random(encoding="lsystem" if k % 3 else "direct") for k in range(2300)]
+    serial = E.encode_population(inds, 8, workers=1)
+    pooled = E.encode_population(inds, 8, workers=3, chunk=200)
+    import copy
+    specs = [build_creature(copy.deepcopy(ind.genome.create(8)).getNodes(), ind.genome.moduleList)[0] for ind in inds]
+    groups = {}
+    for e, s in enumerate(specs):
+        groups.setdefault(lanes_for(s.n_bodies), []).append(e)
+    assert len(serial) == len(pooled) == len(groups)
+    for (m1, i1), (m2, i2), lanes in zip(serial, pooled, sorted(groups)):
+        ref = sorted(groups[lanes], key=lambda e: (specs[e].period, max(specs[e].rounds, default=-1), specs[e].n_bodies))
+        assert i1 == i2 == ref
+        mr = Morphology.from_specs([specs[e] for e in ref], lanes)
+        for k in mr.arrays:
+            assert np.array_equal(m1.arrays[k], mr.arrays[k]) and np.array_equal(m2.arrays[k], mr.arrays[k])
+        assert np.array_equal(m1.n_bodies, mr.n_bodies) and np.array_equal(m2.n_bodies, mr.n_bodies)

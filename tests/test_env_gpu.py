@@ -102,3 +102,26 @@ def test_merged_launch_equals_per_bucket_streams(need_gpu):
     assert all(np.array_equal(x, y) for x, y in zip(b0, b1))
     assert all(np.array_equal(x, y) for x, y in zip(c0, c1))
     assert np.array_equal(f0, f1)
+
+
+def test_array_population_fitness_is_order_independent(need_gpu):
+    """population.LSystemPopulation -> native compiler -> batched episodes: the fitness of an individual does not
+    depend on where it sits in the population (bucket sorting / step groups / index gathering are transparent)."""
+    import torch
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import run_episode
+    from gym_rem2d_amd.population import LSystemPopulation
+    rng = np.random.default_rng(11)
+    pop = LSystemPopulation.random(600, rng, max_modules=15)
+    env = BatchedModular2D()
+
+    def evaluate(p):
+        env.trees = env.robots = None
+        env._upload(p.compile(2), len(p))
+        return run_episode(env, max_steps=400).cpu().numpy()
+    f1 = evaluate(pop)
+    assert np.array_equal(f1, evaluate(pop))
+    perm = rng.permutation(600)
+    assert np.array_equal(evaluate(pop.select(perm)), f1[perm])
+    assert (f1 > 0).sum() > 300 and len(np.unique(f1)) > 100
+    env.close()
