@@ -199,3 +199,39 @@ def run_generations(pop, n_generations, evaluate, rng, morph_rate=0.01, rate=0.0
         if log:
             log("Generation %d : Min %s, Max %s, Avg %s" % history[-1])
     return pop, fit, history
+
+
+def sharded_evaluator(local_eval, group=None, device=None):
+    """evaluate(population) for a torch.distributed job (one process per GPU): every rank holds the whole
+    population as arrays (selection and mutation are replicated from a shared seed, so no genome ever crosses a
+    rank boundary), expresses and evaluates only its contiguous block ``[lo, hi)`` with
+    ``local_eval(LSystemPopulation block) -> fitness[hi-lo]`` and the ranks exchange one all-gather of fp32
+    fitness (REM2D_main.py:256-267 pool.map)."""
+    import torch
+    import torch.distributed as dist
+    from .evaluate import all_gather_fitness, shard_range
+
+    def evaluate(pop):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        lo, hi = shard_range(len(pop), rank, world)
+        local = local_eval(pop.select(np.arange(lo, hi))) if hi > lo else np.zeros(0, dtype=np.float32)
+        local = torch.as_tensor(np.asarray(local, dtype=np.float32), device=device)
+        return all_gather_fitness(local, len(pop), group).cpu().numpy().astype(np.float64)
+    return evaluate
+
+
+def gpu_evaluator(env=None, max_steps=None, n_threads=0):
+    """local_eval for sharded_evaluator / evaluate for run_generations on one GPU: native expression, upload,
+    whole episodes (evaluate()'s rule), fitness as float64 numpy."""
+    from .env import BatchedModular2D
+    from .evaluate import EPISODE_CAP, run_episode
+    holder = {"env": env}
+
+    def evaluate(pop):
+        if holder["env"] is None:
+            holder["env"] = BatchedModular2D()
+        e = holder["env"]
+        e.trees = e.robots = None
+        e._upload(pop.compile(n_threads), len(pop))
+        return run_episode(e, max_steps if max_steps is not None else EPISODE_CAP).cpu().numpy()
+    return evaluate

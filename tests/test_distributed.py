@@ -70,3 +70,49 @@ def test_sharded_evaluation_gloo(tmp_path, oracle):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "fit%d.npy" % r))
         assert got.shape == (n_total,) and np.array_equal(got, ref)
+
+
+def _ea_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    g.build()
+    from gym_rem2d_amd.population import LSystemPopulation, run_generations, sharded_evaluator
+
+    def local_eval(block):   # CPU stand-in for the batched episode: any deterministic function of the phenotype
+        out = np.zeros(len(block), dtype=np.float32)
+        for m, idx in block.compile(1):
+            x = m.arrays["x"].reshape(m.n_envs, m.lanes).astype(np.float64)
+            out[np.asarray(idx)] = (x.sum(axis=1) + m.n_bodies).astype(np.float32)
+        return out
+
+    rng = np.random.default_rng(7)          # the same seed on every rank: replicated selection / mutation
+    pop = LSystemPopulation.random(301, rng, max_modules=15)
+    pop, fit, hist = run_generations(pop, 3, sharded_evaluator(local_eval), rng, 0.2, 0.2, 0.2)
+    np.save(os.path.join(out_dir, "ea_fit%d.npy" % rank), fit)
+    np.save(os.path.join(out_dir, "ea_angle%d.npy" % rank), pop.a["mod_angle"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_array_ea_gloo(tmp_path):
+    """Array EA on 2 ranks: replicated variation + sharded evaluation + one fitness all-gather per generation gives
+    every rank the same population and the same fitness as a single process."""
+    world, port = 2, _free_port()
+    mp.spawn(_ea_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from gym_rem2d_amd.population import LSystemPopulation, run_generations
+
+    def evaluate(p):
+        out = np.zeros(len(p), dtype=np.float32)
+        for m, idx in p.compile(1):
+            x = m.arrays["x"].reshape(m.n_envs, m.lanes).astype(np.float64)
+            out[np.asarray(idx)] = (x.sum(axis=1) + m.n_bodies).astype(np.float32)
+        return out.astype(np.float64)
+    rng = np.random.default_rng(7)
+    pop = LSystemPopulation.random(301, rng, max_modules=15)
+    pop, fit, hist = run_generations(pop, 3, evaluate, rng, 0.2, 0.2, 0.2)
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "ea_fit%d.npy" % r)), fit)
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "ea_angle%d.npy" % r)), pop.a["mod_angle"])
+    assert hist[-1][3] >= hist[0][3]   # selection pushes the mean up
