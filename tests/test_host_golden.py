@@ -190,3 +190,32 @@ def test_pipeline_schedule_keeps_sequential_order():
     assert any(s.period >= 4 for s in specs)
     for s in specs:
         _check_pipeline(s)
+
+
+def test_reference_checkpoint_loads_and_expresses_identically():
+    """tests/golden/reference_population.pkl was pickled from the reference's own classes
+    (tools/capture_golden.py; module paths Encodings.*, gym_rem2D.morph.*, Controller.*, REM2D_main).
+    compat.load_reference_pickle maps them onto this package; the loaded genomes must express to the layouts
+    the reference produced for the same seeds, and survive mutation + the native compiler."""
+    from gym_rem2d_amd.compat import Encoding_Type, load_reference_pickle
+    from gym_rem2d_amd.ea import Individual
+    pop = load_reference_pickle(os.path.join(GOLD, "reference_population.pkl"))
+    assert len(pop) == 10 and all(isinstance(i, Individual) for i in pop)
+    assert [i.fitness for i in pop] == [s + 0.5 for s in range(6)] + [s + 0.5 for s in range(4)]
+    assert pop[0].ENCODING_TYPE is Encoding_Type.LSYSTEM and pop[-1].ENCODING_TYPE is Encoding_Type.DIRECT
+    for enc, inds in (("lsystem", pop[:6]), ("direct", pop[6:])):
+        cases = load("layout_%s.json" % enc)["cases"]
+        for seed, ind in enumerate(inds):
+            tree = ind.genome.create(ind.tree_depth)
+            _check_tree(tree.getNodes(), cases[seed]["tree"])
+            t2 = copy.deepcopy(tree)
+            spec, _, _ = build_creature(t2.getNodes(), ind.genome.moduleList)
+            _check_layout(spec, t2.getNodes(), cases[seed]["layout"])
+    # loaded genomes are live objects of this package: they mutate and feed the array / native path
+    random.seed(99)
+    pop[0].mutate(0.5, 0.5, 0.5)
+    from gym_rem2d_amd.encode import lsystem_genome_arrays
+    a = lsystem_genome_arrays([i.genome for i in pop[:6]])
+    assert a["mod_shape"].shape == (6, 8) and a["rule_n"].max() <= 3
+    with pytest.raises(Exception, match="no counterpart"):   # a genome type this build has no class for
+        load_reference_pickle(b"cEncodings.Network_Encoding\nNN_enc\n.")

@@ -352,6 +352,43 @@ def main():
         div[enc] = dict(n=n_seeds, positions=positions, diversity=[float(v) for v in ADA.tree_edit_distance(pop)])
     with open(os.path.join(OUT, "diversity.json"), "w") as f:
         json.dump(div, f)
+
+    # ---- a population checkpoint as the reference pickles it (REM2D_main.py:311-329): reference classes,
+    # reference module paths; REM2D_main itself needs deap, so its two small classes are stood in for here
+    import enum
+    import pickle
+    main_mod = types.ModuleType("REM2D_main")
+
+    class Encoding_Type(enum.Enum):
+        DIRECT = 0
+        LSYSTEM = 1
+        NEURAL_NETWORK = 2
+        CELLULAR_ENCODING = 3
+
+    class Individual:
+        def __init__(self):
+            self.genome = None
+            self.fitness = 0
+    for c in (Encoding_Type, Individual):
+        c.__module__, c.__qualname__ = "REM2D_main", c.__name__
+        setattr(main_mod, c.__name__, c)
+    sys.modules["REM2D_main"] = main_mod
+    pop = []
+    for enc, seeds in (("lsystem", range(6)), ("direct", range(4))):
+        for seed in seeds:
+            random.seed(seed)
+            ml = module_list()
+            ind = Individual()
+            ind.ENCODING_TYPE = Encoding_Type.DIRECT if enc == "direct" else Encoding_Type.LSYSTEM
+            ind.genome = de.DirectEncoding(ml) if enc == "direct" else ls.LSystem(ml)
+            if enc == "lsystem" and seed % 2 == 1:
+                for _ in range(3):
+                    ind.genome.mutate(0.5, 0.5, 0.5)
+            ind.tree_depth = 8
+            ind.fitness = float(seed) + 0.5
+            pop.append(ind)
+    with open(os.path.join(OUT, "reference_population.pkl"), "wb") as f:
+        pickle.dump(pop, f, protocol=2)
     print("wrote fixtures to", os.path.normpath(OUT))
 
 
