@@ -44,6 +44,11 @@ def _class_map():
     }
 
 
+class Opaque:
+    """Stands in for helper objects of the reference's legacy 3D package that 2D modules still carry along
+    (``Circular2D.orientation`` is a ``gym_rem.utils.Rot``, circular_module.py:37); the 2D path never reads them."""
+
+
 class ReferenceUnpickler(pickle.Unpickler):
     def __init__(self, file):
         super().__init__(file)
@@ -54,6 +59,8 @@ class ReferenceUnpickler(pickle.Unpickler):
         if hit is not None:
             return hit
         top = module.split(".")[0].lower()
+        if top == "gym_rem":
+            return Opaque
         if top in ("encodings", "gym_rem2d", "controller", "tree", "rem2d_main", "neat"):
             raise pickle.UnpicklingError("reference class %s.%s has no counterpart in gym_rem2d_amd "
                                          "(supported: direct and L-system genomes)" % (module, name))
