@@ -64,6 +64,7 @@ def lib():
         L.rem2d_oracle_set_gravity.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.rem2d_oracle_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         L.rem2d_oracle_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_env_step_ex.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         for f in ("num_bodies", "num_joints", "position_iterations", "toi_events"):
             getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p]
         for f in ("get_bodies", "get_mass", "get_joints"):
@@ -161,6 +162,11 @@ class World:
 
     def step(self, dt=1.0 / 50, vel_iters=180, pos_iters=60):
         lib().rem2d_oracle_world_step(self.h, dt, vel_iters, pos_iters)
+
+    def env_step_ex(self, dt, vel_iters, pos_iters):
+        r, d = C.c_double(), C.c_int()
+        lib().rem2d_oracle_env_step_ex(self.h, dt, vel_iters, pos_iters, C.byref(r), C.byref(d))
+        return r.value, d.value
 
     def env_step(self):
         r = C.c_double()

@@ -2737,6 +2737,10 @@ static void world_solve_toi(o_world *w, const step_t *step) {
 #define FPS 50
 #define WOD_SPEED 0.04
 void rem2d_oracle_env_step(o_world *w, double *reward_out, int *done_out) {
+    rem2d_oracle_env_step_ex(w, (float)(1.0 / FPS), 6 * 30, 2 * 30, reward_out, done_out); /* :634 */
+}
+/* the same step with explicit b2World::Step arguments (mirror of rem2d_world_step_ex) */
+void rem2d_oracle_env_step_ex(o_world *w, float dt, int velIters, int posIters, double *reward_out, int *done_out) {
     w->wod += WOD_SPEED; /* :613-614 */
     /* controller sweep (:620-623) in node order, then PID -> motorSpeed (:631-632) */
     double cvals[O_MAX_BODIES];
@@ -2753,7 +2757,7 @@ void rem2d_oracle_env_step(o_world *w, double *reward_out, int *done_out) {
         double speed = angleDifference * 1.9;
         rem2d_oracle_set_motor_speed(w, i, (float)speed);
     }
-    rem2d_oracle_world_step(w, (float)(1.0 / FPS), 6 * 30, 2 * 30); /* :634 */
+    rem2d_oracle_world_step(w, dt, velIters, posIters);
     double reward = 0.0;
     int done = 0;
     if (w->nbody > 0) {

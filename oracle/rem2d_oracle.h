@@ -71,6 +71,7 @@ void rem2d_oracle_set_gravity(o_world *, float gx, float gy);
 void rem2d_oracle_world_step(o_world *, float dt, int velIters, int posIters);
 /* Modular2D.step (Modular2DEnv.py:607-653): wod, controllers, PID, Step(1/50,180,60), reward/done */
 void rem2d_oracle_env_step(o_world *, double *reward, int *done);
+void rem2d_oracle_env_step_ex(o_world *, float dt, int velIters, int posIters, double *reward, int *done);
 
 int rem2d_oracle_num_bodies(const o_world *);
 int rem2d_oracle_num_joints(const o_world *);

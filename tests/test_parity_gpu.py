@@ -302,3 +302,82 @@ def test_gpu_matches_committed_trajectory_digests(gpu):
         assert int(w.view("err").max()) == 0
         w.close()
         assert got == gold[name]["sha256"], name
+
+
+@pytest.mark.parametrize("vel_iters,pos_iters,flags", [(8, 3, 0), (40, 100, 1), (3, 70, 0)])
+def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iters, pos_iters, flags):
+    """rem2d_world_step_ex with Box2D's usual (8, 3) and with more than 64 position iterations (the pipelined
+    position solver keeps its per-iteration flags in a 64-entry ring) against the oracle's env_step_ex."""
+    morph = _populations()["lsystem_k16"]
+    ot = oracle_terrain(oracle, rough_terrain)
+    steps = 120
+    w = gpu(morph.n_envs, morph.lanes, flags)
+    w.set_terrain(rough_terrain)
+    w.reset(morph)
+    w.step_ex(steps, 1.0 / 50, vel_iters, pos_iters)
+    got = w.bodies()
+    used = w.view("positers").cpu().numpy()
+    assert int(w.view("err").max()) == 0
+    w.close()
+    d = morph.as_dict()
+    for e in range(morph.n_envs):
+        ow = oracle.World.from_morph(ot, d, e, flags)
+        for _ in range(steps):
+            ow.env_step_ex(1.0 / 50, vel_iters, pos_iters)
+        ref = ow.bodies()
+        assert np.array_equal(got[e, : ref.shape[0]], ref), e
+        assert used[e] == ow.position_iterations
+    print('position iterations used: max %d of %d' % (used.max(), pos_iters))
+    assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
+
+
+def test_split_pipeline_matches_committed_digests(gpu):
+    """REM2D_PIPELINE=1 (pre / constraint-lane velocity / post kernels) is read once per process, so it runs in
+    a child process: same committed digests as the fused path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import make_trajectory_digest as D\n"
+        "from gym_rem2d_amd.world import BatchedWorld\n"
+        "out = {}\n"
+        "for name, pop, ter, flags, steps in D.CASES:\n"
+        "    m, t = D.population(pop), D.terrain(ter)\n"
+        "    w = BatchedWorld(m.n_envs, m.lanes, flags); w.set_terrain(t); w.reset(m); w.step(steps)\n"
+        "    out[name] = D.digest(w.bodies(), m.n_bodies, w.view('reward').cpu().numpy(), w.view('everdone').cpu().numpy(),\n"
+        "                         w.view('fitness').cpu().numpy())\n"
+        "    w.close()\n"
+        "print('DIGESTS ' + json.dumps(out))\n") % (root, os.path.join(root, "tools"))
+    env = dict(os.environ, REM2D_PIPELINE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
+    got = json.loads(line[len("DIGESTS "):])
+    with open(os.path.join(root, "tests", "golden", "trajectory_digest.json")) as f:
+        gold = json.load(f)["cases"]
+    assert got == {k: v["sha256"] for k, v in gold.items()}
+
+
+def test_worlds_step_argument_errors(gpu, flat_terrain):
+    import ctypes as C
+    from gym_rem2d_amd import _lib, synthetic
+    m = synthetic.chain_population(4, 4, "top")
+    a, b = gpu(4, m.lanes, 0), gpu(4, m.lanes, _lib.FLAG_CONTINUOUS)
+    for w in (a, b):
+        w.set_terrain(flat_terrain)
+        w.reset(m)
+    L = _lib.lib()
+    st = a._stream()
+    two = (C.c_void_p * 2)(a.h, b.h)
+    assert L.rem2d_worlds_step(two, 2, 1, st) != 0 and b"CONTINUOUS" in L.rem2d_last_error()
+    nine = (C.c_void_p * 9)(*([a.h] * 9))
+    assert L.rem2d_worlds_step(nine, 9, 1, st) != 0 and b"too many" in L.rem2d_last_error()
+    assert L.rem2d_worlds_step(two, 0, 1, st) != 0
+    c = gpu(4, m.lanes, 0)
+    pair = (C.c_void_p * 2)(a.h, c.h)
+    assert L.rem2d_worlds_step(pair, 2, 1, st) != 0 and b"set_terrain" in L.rem2d_last_error()   # c has no terrain yet
+    for w in (a, b, c):
+        w.close()
