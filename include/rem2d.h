@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 1
+#define REM2D_ABI_VERSION 2 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem */
 
 enum {
     REM2D_OK = 0,
