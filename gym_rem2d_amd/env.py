@@ -51,6 +51,8 @@ class WallOfDeath:
 
 
 class BatchedModular2D:
+    MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
+
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
         from . import _lib
@@ -134,10 +136,12 @@ class BatchedModular2D:
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
             cuts = [morph.n_envs * g // groups for g in range(groups + 1)] if morph.n_envs >= 4 * groups else [0, morph.n_envs]
-            for g in range(len(cuts) - 1):
-                lo, hi = cuts[g], cuts[g + 1]
-                if hi <= lo:
-                    continue
+            pieces = []
+            for g in range(len(cuts) - 1):   # one world addresses its lanes with 32-bit offsets: <= MAX_WORLD_LANES
+                per = max(1, self.MAX_WORLD_LANES // morph.lanes)
+                for lo in range(cuts[g], cuts[g + 1], per):
+                    pieces.append((g, lo, min(cuts[g + 1], lo + per)))
+            for g, lo, hi in pieces:
                 part = morph if (lo == 0 and hi == morph.n_envs) else morph.take(np.arange(lo, hi))
                 w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device)
                 w.set_terrain(self._terrain())
