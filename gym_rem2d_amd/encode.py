@@ -46,6 +46,12 @@ def encode_population(individuals, tree_depth=None, workers=None, chunk=256):
     n = len(individuals)
     if workers is None:
         workers = min(os.cpu_count() or 1, 64)
+        try:   # forking a process that holds a GPU context costs ~0.2 s per worker
+            import torch
+            if torch.cuda.is_initialized():
+                workers = min(workers, 8)
+        except Exception:  # noqa: BLE001
+            pass
     ranges = [(lo, min(n, lo + chunk), tree_depth) for lo in range(0, n, chunk)]
     _POP = individuals
     try:
