@@ -398,26 +398,46 @@ DEV bool toi_far_apart(const Proxy &pA, const Proxy &pB, const Sweep &sw, int sh
             // core distance at the sweep start, and no point of the body moves further than
             // |c - c0| + coreR * |a - a0| during the sweep, so distance(t) >= lb0 - that.  Axes tried:
             // the static shape's face normals and the body's own axes.
-            Rot q0 = rot_set(sw.a0);
-            float lb0 = -FLT_MAX;
-            V2 bv[4];
+            // Tighter for the static shape's own axes u, which do not move.  A body vertex follows
+            // c(t) + R(a(t)) r with c and a interpolated linearly (b2Sweep), so u.vertex(t) is a linear function of
+            // t plus a sinusoid of amplitude <= |r| sampled over an angle |a - a0|: it stays within
+            // |r| (1 - cos(|a - a0| / 2)) <= coreR (a - a0)^2 / 8 of the chord between its values at t = 0 and t = 1.
+            // Hence separation_u(t) >= min(separation_u(0), separation_u(1)) - coreR (a - a0)^2 / 8 for all t: a body
+            // that slides or turns next to an edge without coming closer is skipped however far it moves.
+            Rot q0 = rot_set(sw.a0), q1 = rot_set(sw.a);
+            float lb0 = -FLT_MAX, lbTight = -FLT_MAX;
+            const V2 dc = vsub(sw.c, sw.c0);
+            const float da = sw.a - sw.a0;
+            const float rot = coreR * fabs32(da);
+            const float sag = coreR * (da * da) * 0.125f;
+            V2 bv[4], bw[4];
             const int nb = pB.count;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bv[k] = xmul(q0, sw.c0, pB.v[k < nb ? k : 0]);
+            for (int k = 0; k < 4; ++k) {
+                bv[k] = xmul(q0, sw.c0, pB.v[k < nb ? k : 0]);
+                bw[k] = xmul(q1, sw.c, pB.v[k < nb ? k : 0]);
+            }
             if (pA.count == 2) { // edge: +-normal, and the edge direction beyond either end
                 V2 e = vsub(pA.v[1], pA.v[0]);
                 vnormalize(e);
                 V2 n = mk(e.y, -e.x);
                 float lo = FLT_MAX, hi = -FLT_MAX, tlo = FLT_MAX, thi = -FLT_MAX;
+                float lo1 = FLT_MAX, hi1 = -FLT_MAX, tlo1 = FLT_MAX, thi1 = -FLT_MAX;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float d = vdot(n, vsub(bv[k], pA.v[0]));
                     lo = fmin32(lo, d); hi = fmax32(hi, d);
                     float td = vdot(e, vsub(bv[k], pA.v[0]));
                     tlo = fmin32(tlo, td); thi = fmax32(thi, td);
+                    float d1 = vdot(n, vsub(bw[k], pA.v[0]));
+                    lo1 = fmin32(lo1, d1); hi1 = fmax32(hi1, d1);
+                    float td1 = vdot(e, vsub(bw[k], pA.v[0]));
+                    tlo1 = fmin32(tlo1, td1); thi1 = fmax32(thi1, td1);
                 }
                 float elen = vdot(e, vsub(pA.v[1], pA.v[0]));
                 lb0 = fmax32(fmax32(lo, -hi), fmax32(tlo - elen, -thi));
+                lbTight = fmax32(fmax32(fmin32(lo, lo1), -fmax32(hi, hi1)),
+                                 fmax32(fmin32(tlo, tlo1) - elen, -fmax32(thi, thi1))) - sag;
             } else { // static box: its four face normals
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -425,10 +445,14 @@ DEV bool toi_far_apart(const Proxy &pA, const Proxy &pB, const Sweep &sw, int sh
                     V2 ed = vsub(b2, a);
                     vnormalize(ed);
                     V2 n = mk(ed.y, -ed.x);
-                    float lo = FLT_MAX;
+                    float lo = FLT_MAX, lo1 = FLT_MAX;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) lo = fmin32(lo, vdot(n, vsub(bv[k], a)));
+                    for (int k = 0; k < 4; ++k) {
+                        lo = fmin32(lo, vdot(n, vsub(bv[k], a)));
+                        lo1 = fmin32(lo1, vdot(n, vsub(bw[k], a)));
+                    }
                     lb0 = fmax32(lb0, lo);
+                    lbTight = fmax32(lbTight, fmin32(lo, lo1) - sag);
                 }
             }
             if (shape == SHAPE_BOX) { // the body's axes against the static shape's vertices
@@ -443,8 +467,8 @@ DEV bool toi_far_apart(const Proxy &pA, const Proxy &pB, const Sweep &sw, int sh
                 }
                 lb0 = fmax32(lb0, fmax32(fmax32(xlo - hx, -xhi - hx), fmax32(ylo - hy, -yhi - hy)));
             }
-            float maxDisp = vlen(vsub(sw.c, sw.c0)) + coreR * fabs32(sw.a - sw.a0);
-            farApart = lb0 - maxDisp > need + 0.002f;
+            float maxDisp = vlen(dc) + rot;
+            farApart = (lb0 - maxDisp > need + 0.002f) || (lbTight > need + 0.002f);
         }
     }
     return farApart;
