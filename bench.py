@@ -47,8 +47,8 @@ def valu_flops_per_env_step(n_bodies, vel_iters=180):
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_e_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command)."""
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+    (profiles/r01_f_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command)."""
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
