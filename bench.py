@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-groups", type=int, default=None,
                     help="independent halves/thirds of the population stepped on separate streams (default: automatic)")
-    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1],
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2],
                     help="0 = fused rem2d_step_kernel, 1 = split pre/vel/post pipeline (default: the library's default)")
     ap.add_argument("--discrete", action="store_true",
                     help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
@@ -248,13 +248,13 @@ def main():
         if max(len(g) for g in env.groups) > 1:
             kname = "rem2d_step_multi_kernel"
         else:
-            kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % morphs[0].lanes
+            kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") in ("1", "2") else "rem2d_step_kernel<%d>" % morphs[0].lanes
     else:
         ms, launches, wmax = max(times, key=lambda k: k[0])
         m = morphs[[w for w, _ in env.worlds].index(wmax)]
         bytes_per_step = float(algorithmic_bytes(m.n_bodies).sum())
         flops_per_step = float(valu_flops_per_env_step(m.n_bodies).sum())
-        kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") == "1" else "rem2d_step_kernel<%d>" % m.lanes
+        kname = "rem2d_vel_kernel" if os.environ.get("REM2D_PIPELINE") in ("1", "2") else "rem2d_step_kernel<%d>" % m.lanes
     bytes_per_step_all = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
     # algorithmic bytes of one launch / its average duration == bytes of all timed launches / their total duration
     avg_ms = ms / max(1, launches)

@@ -72,6 +72,7 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_position.h"
 #include "rem2d_kernels.h"
 #include "rem2d_pipeline.h"
+#include "rem2d_vel3.h"
 #include "rem2d_diversity.h"
 
 // =====================================================================================
@@ -326,6 +327,26 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
     return REM2D_OK;
 }
 
+// Lanes per creature (Q) and creatures per wavefront (cw) of rem2d_vel3_kernel.  Q = K/2 always suffices (the
+// joints of one schedule phase of a creature are a matching of its tree); REM2D_VEL3_Q overrides it for
+// populations whose largest phase class is known to be smaller (a too small Q is reported as SOLVER_OVERFLOW).
+static Vel3Args vel3_args(int lanes, int vel_iters, float dt, float friction) {
+    static const int qEnv = getenv("REM2D_VEL3_Q") ? atoi(getenv("REM2D_VEL3_Q")) : 0;
+    Vel3Args A;
+    A.K = lanes;
+    A.Q = lanes / 2 > 0 ? lanes / 2 : 1;
+    if (qEnv > 0 && qEnv < A.Q) A.Q = qEnv;
+    int cw = WAVE / A.Q;
+    if (cw * lanes > V3_MAX_BODIES) cw = V3_MAX_BODIES / lanes;
+    // keep whole 64-lane passes: cw * K must be a multiple of 64
+    while (cw > 1 && (cw * lanes) % WAVE != 0) --cw;
+    A.cw = cw;
+    A.velIters = vel_iters;
+    A.dt = dt;
+    A.friction = friction;
+    return A;
+}
+
 extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                                    void *stream) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
@@ -337,8 +358,8 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     // Default: the fused rem2d_step_kernel (one launch for all of Modular2D.step).  REM2D_PIPELINE=1 selects
     // the split pipeline pre -> vel -> post whose velocity kernel maps lanes to constraints: fewer
     // instructions, but bound by the barrier-to-barrier latency of its slots -- measured slower so far.
-    static const bool splitEnv = getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 1;
-    const bool split = splitEnv;
+    static const int pipelineEnv = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 0;
+    const bool split = pipelineEnv == 1 || pipelineEnv == 2; // 2: the wave-level velocity kernel rem2d_vel3_kernel
     StepArgs A;
     A.nSteps = (continuous || split) ? 1 : n_steps;
     A.dt = dt;
@@ -374,8 +395,14 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
             V.dt = dt;
             V.friction = w->T.friction;
             if (w->timing) HIP_TRY(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(rem2d_vel_kernel, dim3(((unsigned)w->L.Lp + VEL_THREADS - 1) / VEL_THREADS), dim3(VEL_THREADS), 0,
-                               st, w->S, V);
+            if (pipelineEnv == 2) {
+                Vel3Args V3 = vel3_args(w->cfg.lanes, vel_iters, dt, w->T.friction);
+                const unsigned nb = (unsigned)(V3.cw * V3.K);
+                hipLaunchKernelGGL(rem2d_vel3_kernel, dim3(((unsigned)w->L.Lp + nb - 1) / nb), dim3(WAVE), 0, st, w->S, V3);
+            } else {
+                hipLaunchKernelGGL(rem2d_vel_kernel, dim3(((unsigned)w->L.Lp + VEL_THREADS - 1) / VEL_THREADS), dim3(VEL_THREADS),
+                                   0, st, w->S, V);
+            }
             if (w->timing) HIP_TRY(hipEventRecord(e1, st));
             LAUNCH_BY_LANES(rem2d_post_kernel);
         } else {
