@@ -14,6 +14,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "rem2d.hip")
 FLAG_CONTINUOUS = 1
 FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
+FLAG_SKIP_FROZEN = 8
 
 CONTACT_SLOTS = 24
 MAX_WORLDS_PER_STEP = 8

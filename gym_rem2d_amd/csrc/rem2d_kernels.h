@@ -44,6 +44,10 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     const unsigned gl0 = block * WAVE + lane;
     const unsigned env0 = gl0 / K;
     if (gl0 == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // evaluate() has left its loop for every creature of this wavefront
+        const unsigned env = env0;
+        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return;
+    }
     unsigned gl = gl0, env = env0;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
@@ -531,6 +535,9 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
     const unsigned env = gl / K;
     const int sub = lane & (K - 1);
     const unsigned Lp = S.Lp;
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) {
+        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return; // the step kernel skipped this wavefront too
+    }
     const int shape = LI(L_SHAPE);
     const float px = LF(L_PX);
     bool heavy = false;

@@ -97,7 +97,8 @@ def run_ea(config=None, population=None, evaluate_batch=None, seed=None, save_di
     if evaluate_batch is None:
         from .evaluate import evaluate_population
         from .env import BatchedModular2D
-        env = BatchedModular2D()
+        from . import _lib
+        env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
 
         def evaluate_batch(inds):
             return evaluate_population(inds, tree_depth=tree_depth, env=env)

@@ -13,6 +13,8 @@ import math
 import numpy as np
 import torch
 
+from . import _lib
+
 EPISODE_CAP = 2500  # wall of death advances 0.04/step and the goal is x > 100
 
 
@@ -73,6 +75,8 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
     from .env import BatchedModular2D
     own = env is None
     if own:
+        # fitness is all that leaves this function: creatures whose fitness is final need no more steps
+        env_kw.setdefault("flags", _lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
         env = BatchedModular2D(**env_kw)
     env.trees = env.robots = None
     from .encodings.lsystem import LSystem

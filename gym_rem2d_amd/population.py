@@ -229,7 +229,8 @@ def gpu_evaluator(env=None, max_steps=None, n_threads=0):
 
     def evaluate(pop):
         if holder["env"] is None:
-            holder["env"] = BatchedModular2D()
+            from . import _lib
+            holder["env"] = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
         e = holder["env"]
         e.trees = e.robots = None
         e._upload(pop.compile(n_threads), len(pop))

@@ -41,6 +41,10 @@ enum {
 #define REM2D_FLAG_CONTINUOUS 1u         /* b2World continuousPhysics (SolveTOI) */
 #define REM2D_FLAG_SLEEP_RESET_ALWAYS 2u /* b2Body::SetAwake(true) always zeroes sleepTime */
 #define REM2D_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
+/* evaluate() leaves its loop once an individual's fitness is final (REM2D_main.py:366-372: reward < -10 or
+ * > ENV_LENGTH).  With this flag a wavefront whose creatures are ALL in that state (REM2D_F_FROZEN) is not
+ * stepped any more; fitness is unaffected, the bodies of such creatures simply stop where they were. */
+#define REM2D_FLAG_SKIP_FROZEN 8u
 
 #define REM2D_MAX_LANES 64
 #define REM2D_CONTACT_SLOTS 24 /* broadphase pair slots per body */

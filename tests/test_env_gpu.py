@@ -125,3 +125,25 @@ def test_array_population_fitness_is_order_independent(need_gpu):
     assert np.array_equal(evaluate(pop.select(perm)), f1[perm])
     assert (f1 > 0).sum() > 300 and len(np.unique(f1)) > 100
     env.close()
+
+
+def test_skip_frozen_keeps_fitness_and_stops_stepping(need_gpu):
+    """REM2D_FLAG_SKIP_FROZEN: wavefronts whose creatures all have a final fitness are no longer stepped; the
+    fitness of every creature is the same as without the flag."""
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import run_episode
+    from gym_rem2d_amd.population import LSystemPopulation
+    rng = np.random.default_rng(5)
+    pop = LSystemPopulation.random(3000, rng, max_modules=15)
+    out = []
+    for flags in (_lib.FLAG_CONTINUOUS, _lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN):
+        env = BatchedModular2D(flags=flags)
+        env._upload(pop.compile(2), len(pop))
+        fit = run_episode(env, max_steps=600).cpu().numpy()
+        out.append((fit, env.steps.cpu().numpy(), env.frozen.cpu().numpy()))
+        env.close()
+    (f0, s0, z0), (f1, s1, z1) = out
+    assert np.array_equal(f0, f1) and np.array_equal(z0, z1)
+    assert s0.min() == s0.max()                       # without the flag everybody is stepped to the end
+    assert s1.max() <= s0.max() and (s1 < s0).mean() > 0.3   # with it, most creatures stopped early

@@ -74,7 +74,8 @@ def main_arrays(args):
     import torch
     from gym_rem2d_amd.env import BatchedModular2D
     from gym_rem2d_amd.evaluate import run_episode
-    env = BatchedModular2D()
+    from gym_rem2d_amd import _lib
+    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | (0 if os.environ.get('REM2D_NO_SKIP') else _lib.FLAG_SKIP_FROZEN))
     rows, fit = [], None
     for gen in range(args.generations):
         t0 = time.time()

@@ -50,3 +50,35 @@ for c in range(4):
     nb = (sel > 0).sum(1)
     tot += np.ceil(nb / 64.0) * sel.max(1)
 print("4-wave workgroup, bodies compacted per phase: solves per iteration per workgroup %.2f (now %.2f)" % (tot.mean(), solves[: g * 4].reshape(g, 4).sum(1).mean()))
+# ---- what a per-step cyclic shift of every creature's schedule would buy: greedy alignment of the
+# creatures' touching-phase masks inside each wavefront
+cpw = 64 // K
+ntc = ntouch[: nw * 64].reshape(nw, cpw, K)
+phc = phase[: nw * 64].reshape(nw, cpw, K)
+Pc = P[: nw * 64].reshape(nw, cpw, K).max(2)
+aligned = np.zeros(nw)
+weighted_now = np.zeros(nw); weighted_al = np.zeros(nw)
+for wv in range(0, nw, max(1, nw // 1500)):
+    U = {}
+    per = int(Pc[wv].max())
+    if per <= 0:
+        continue
+    slots_max = np.zeros(per, dtype=np.int64)
+    for c in range(cpw):
+        m = np.zeros(per, dtype=np.int64)
+        for k in range(K):
+            if ntc[wv, c, k] > 0:
+                m[phc[wv, c, k] % per] = max(m[phc[wv, c, k] % per], ntc[wv, c, k])
+        best, bs = None, 0
+        for s in range(per):
+            r = np.roll(m, s)
+            cost = np.maximum(slots_max, r).sum()
+            if best is None or cost < best:
+                best, bs = cost, s
+        slots_max = np.maximum(slots_max, np.roll(m, bs))
+    aligned[wv] = (slots_max > 0).sum()
+    weighted_al[wv] = slots_max.sum()
+    weighted_now[wv] = solves[wv]
+sel = aligned > 0
+print("sampled waves %d: contact slots per iteration now %.2f -> aligned %.2f; solves executed now %.2f -> aligned %.2f" %
+      (sel.sum(), slots[sel].mean(), aligned[sel].mean(), weighted_now[sel].mean(), weighted_al[sel].mean()))
