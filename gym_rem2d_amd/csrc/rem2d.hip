@@ -73,6 +73,7 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_kernels.h"
 #include "rem2d_pipeline.h"
 #include "rem2d_vel3.h"
+#include "rem2d_vel4.h"
 #include "rem2d_diversity.h"
 
 // =====================================================================================
@@ -96,12 +97,16 @@ struct rem2d_world {
     State S;
     Terrain T;
     float *terrainBuf;
+    int *tilesDev; // [nTiles + 1] creature index where each tile of rem2d_vel4_kernel starts
+    int nTiles;
     bool haveTerrain, haveReset;
     bool timing;
-    hipEvent_t ev0, ev1;
     double accumMs;
     int64_t launches;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    // event pairs around the dominant kernel of each launch; created by rem2d_world_enable_timing (outside any timed
+    // region), recorded by the step calls, read back by rem2d_world_kernel_time_ms
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
+    int evUsed;
 };
 
 extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
@@ -154,6 +159,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->terrainBuf = nullptr;
     w->haveTerrain = w->haveReset = false;
     w->timing = false;
+    w->evUsed = 0;
     w->accumMs = 0.0;
     w->launches = 0;
     bind_state(w);
@@ -170,28 +176,152 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMemset(scratch): ") + hipGetErrorString(e));
     }
+    // default tiles of the velocity kernel: 128 / lanes creatures each.  The joints of one schedule phase of a creature
+    // are a matching of its tree (<= lanes / 2 of them), so such a tile never has more than 64 joints in a phase;
+    // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
+    {
+        const int per = cfg->lanes >= 128 ? 1 : (128 / cfg->lanes > 0 ? 128 / cfg->lanes : 1);
+        std::vector<int32_t> ts;
+        for (int c = 0; c < L.Np; c += per) ts.push_back(c);
+        ts.push_back(L.Np);
+        w->tilesDev = nullptr;
+        w->nTiles = 0;
+        int rc = rem2d_world_set_tiles(w, ts.data(), (int32_t)ts.size() - 1);
+        if (rc != REM2D_OK) {
+            (void)hipFree(w->S.scr);
+            delete w;
+            return rc;
+        }
+    }
     *out = w;
     return REM2D_OK;
 }
 
+extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_tiles) {
+    if (!w || !tile_start || n_tiles <= 0) return fail(REM2D_E_INVALID, "tiles: NULL table or no tiles");
+    if (tile_start[0] != 0 || tile_start[n_tiles] < w->cfg.n_envs || tile_start[n_tiles] > w->L.Np)
+        return fail(REM2D_E_INVALID, "tiles must cover creatures [0, n_envs) (at most the padded count)");
+    for (int t = 0; t < n_tiles; ++t) {
+        const long long c = (long long)tile_start[t + 1] - tile_start[t];
+        if (c <= 0) return fail(REM2D_E_INVALID, "tile starts must be strictly increasing");
+        if (c * w->cfg.lanes > V4_MAX_BODIES && c != 1) return fail(REM2D_E_INVALID, "a tile holds at most 256 bodies (lanes)");
+    }
+    if (w->cfg.lanes > V4_MAX_BODIES) return fail(REM2D_E_INVALID, "lanes per creature exceed one tile");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    int *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, ((size_t)n_tiles + 1) * sizeof(int)));
+    hipError_t e = hipMemcpy(dev, tile_start, ((size_t)n_tiles + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(REM2D_E_HIP, std::string("hipMemcpy(tiles): ") + hipGetErrorString(e));
+    }
+    if (w->tilesDev) (void)hipFree(w->tilesDev); // hipFree waits for kernels that may still read the old table
+    w->tilesDev = dev;
+    w->nTiles = n_tiles;
+    w->S.tiles = dev;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
+                                int32_t max_creatures, int32_t *tile_start_out, int32_t *n_tiles_out) {
+    if (!parent || !jround || !tile_start_out || !n_tiles_out) return fail(REM2D_E_INVALID, "plan_tiles: NULL argument");
+    if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > V4_MAX_BODIES)
+        return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
+    if (max_creatures <= 0) {
+        static const int envCap = getenv("REM2D_TILE_CREATURES") ? atoi(getenv("REM2D_TILE_CREATURES")) : 0;
+        max_creatures = envCap > 0 ? envCap : 32;
+    }
+    const int capBodies = V4_MAX_BODIES / lanes; // creatures per tile by lanes
+    const int cap = max_creatures < capBodies ? max_creatures : capBodies;
+    int nt = 0;
+    tile_start_out[0] = 0;
+    int first = 0;        // first creature of the open tile
+    int P = 1;            // its period
+    int cnt[V4_SETS];     // its joints per phase
+    for (int s = 0; s < V4_SETS; ++s) cnt[s] = 0;
+    auto creature_period = [&](int e) {
+        int p = 1;
+        if (e < n_envs)
+            for (int k = 0; k < lanes; ++k) {
+                const int q = (jround[(size_t)e * lanes + k] >> 16) & 0xff;
+                p = q > p ? q : p;
+            }
+        return p;
+    };
+    auto add_counts = [&](int e, int period, int *c) { // joints of creature e per phase under `period`
+        if (e >= n_envs) return;
+        for (int k = 0; k < lanes; ++k) {
+            const size_t i = (size_t)e * lanes + k;
+            if (parent[i] < 0) continue;
+            const int ph = (jround[i] & 0xff) % period;
+            if (ph < V4_SETS) c[ph] += 1; // periods beyond V4_SETS are refused by the kernel (REM2D_ERR_SOLVER_OVERFLOW)
+        }
+    };
+    for (int e = 0; e < n_padded; ++e) {
+        const int pe = creature_period(e);
+        bool fits = (e - first) < cap;
+        int c2[V4_SETS], P2 = P;
+        if (fits) {
+            P2 = pe > P ? pe : P;
+            for (int s = 0; s < V4_SETS; ++s) c2[s] = 0;
+            if (P2 != P) {
+                for (int x = first; x < e; ++x) add_counts(x, P2, c2);
+            } else {
+                for (int s = 0; s < V4_SETS; ++s) c2[s] = cnt[s];
+            }
+            add_counts(e, P2, c2);
+            for (int s = 0; s < V4_SETS; ++s) fits = fits && c2[s] <= WAVE;
+        }
+        if (!fits && e > first) { // close the tile before e, start a new one with e
+            tile_start_out[++nt] = e;
+            first = e;
+            P2 = pe;
+            for (int s = 0; s < V4_SETS; ++s) c2[s] = 0;
+            add_counts(e, P2, c2);
+        }
+        P = P2;
+        for (int s = 0; s < V4_SETS; ++s) cnt[s] = c2[s];
+    }
+    tile_start_out[++nt] = n_padded;
+    *n_tiles_out = nt;
+    return REM2D_OK;
+}
+
 static void drain_timing(rem2d_world *w) {
-    for (auto &p : w->pending) {
+    for (int i = 0; i < w->evUsed; ++i) {
+        auto &p = w->evPool[i];
         float ms = 0.0f;
         if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             w->accumMs += ms;
             w->launches += 1;
         }
+    }
+    w->evUsed = 0;
+}
+static void free_timing(rem2d_world *w) {
+    for (auto &p : w->evPool) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
-    w->pending.clear();
+    w->evPool.clear();
+    w->evUsed = 0;
+}
+// first event of the next free pair, or nullptr when timing is off / the pool is used up (those launches go untimed)
+static bool timing_begin(rem2d_world *w, hipStream_t st) {
+    if (!w->timing || w->evUsed >= (int)w->evPool.size()) return false;
+    return hipEventRecord(w->evPool[w->evUsed].first, st) == hipSuccess;
+}
+static void timing_end(rem2d_world *w, hipStream_t st) {
+    (void)hipEventRecord(w->evPool[w->evUsed].second, st);
+    w->evUsed += 1;
 }
 
 extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (!w) return REM2D_OK;
     (void)hipSetDevice(w->cfg.device);
-    drain_timing(w);
+    free_timing(w);
     if (w->S.scr) (void)hipFree(w->S.scr);
+    if (w->tilesDev) (void)hipFree(w->tilesDev);
     if (w->terrainBuf) (void)hipFree(w->terrainBuf);
     delete w;
     return REM2D_OK;
@@ -347,6 +477,62 @@ static Vel3Args vel3_args(int lanes, int vel_iters, float dt, float friction) {
     return A;
 }
 
+// REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = fused
+// rem2d_step_kernel, 1 = split pipeline with the 4-wave rem2d_vel_kernel, 2 = rem2d_vel3_kernel (single world only).
+static int pipeline_mode() {
+    static const int mode = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 3;
+    return mode;
+}
+
+// The tile pipeline for one or several worlds (lane buckets) in one grid per kernel: pre and post run one body per
+// lane; the velocity iterations run one tile per wavefront (rem2d_vel4.h).
+static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float dt, int vel_iters, int pos_iters, hipStream_t st) {
+    Batch B;
+    Vel4Batch VB;
+    memset(&B, 0, sizeof(B));
+    memset(&VB, 0, sizeof(VB));
+    unsigned blocks = 0, tiles = 0;
+    for (int i = 0; i < n_worlds; ++i) {
+        rem2d_world *w = ws[i];
+        B.S[i] = w->S;
+        B.T[i] = w->T;
+        B.lanes[i] = w->cfg.lanes;
+        blocks += (unsigned)w->L.Lp / WAVE;
+        B.blockEnd[i] = blocks;
+        VB.S[i] = w->S;
+        VB.friction[i] = w->T.friction;
+        VB.lanes[i] = w->cfg.lanes;
+        tiles += (unsigned)w->nTiles;
+        VB.tileEnd[i] = tiles;
+    }
+    B.n = VB.n = n_worlds;
+    rem2d_world *w0 = ws[0];
+    const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
+    StepArgs A;
+    A.nSteps = 1;
+    A.dt = dt;
+    A.velIters = vel_iters;
+    A.posIters = pos_iters;
+    A.defer = continuous ? 1 : 0;
+    Vel4Args V;
+    V.velIters = vel_iters;
+    V.dt = dt;
+    const dim3 grid(blocks), block(WAVE);
+    for (int l = 0; l < n_steps; ++l) {
+        hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
+        const bool timed = timing_begin(w0, st);
+        hipLaunchKernelGGL(rem2d_vel4_kernel, dim3(tiles), block, 0, st, VB, V);
+        if (timed) timing_end(w0, st);
+        hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
+        if (continuous) {
+            hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
+            hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
+
 extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                                    void *stream) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
@@ -355,10 +541,8 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
     const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    // Default: the fused rem2d_step_kernel (one launch for all of Modular2D.step).  REM2D_PIPELINE=1 selects
-    // the split pipeline pre -> vel -> post whose velocity kernel maps lanes to constraints: fewer
-    // instructions, but bound by the barrier-to-barrier latency of its slots -- measured slower so far.
-    static const int pipelineEnv = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 0;
+    const int pipelineEnv = pipeline_mode();
+    if (pipelineEnv == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
     const bool split = pipelineEnv == 1 || pipelineEnv == 2; // 2: the wave-level velocity kernel rem2d_vel3_kernel
     StepArgs A;
     A.nSteps = (continuous || split) ? 1 : n_steps;
@@ -372,11 +556,7 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     for (int l = 0; l < launches; ++l) {
         // timing brackets the dominant kernel only (bench.py's roofline leg): the fused step kernel, or the
         // velocity kernel of the split pipeline
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (w->timing) {
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-        }
+        bool timed = false;
         if (split) {
 #define LAUNCH_K(NAME, KK) hipLaunchKernelGGL((NAME<KK>), grid, block, 0, st, w->S, w->T, A)
 #define LAUNCH_BY_LANES(NAME)                  \
@@ -394,7 +574,7 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
             V.velIters = vel_iters;
             V.dt = dt;
             V.friction = w->T.friction;
-            if (w->timing) HIP_TRY(hipEventRecord(e0, st));
+            timed = timing_begin(w, st);
             if (pipelineEnv == 2) {
                 Vel3Args V3 = vel3_args(w->cfg.lanes, vel_iters, dt, w->T.friction);
                 const unsigned nb = (unsigned)(V3.cw * V3.K);
@@ -403,10 +583,10 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
                 hipLaunchKernelGGL(rem2d_vel_kernel, dim3(((unsigned)w->L.Lp + VEL_THREADS - 1) / VEL_THREADS), dim3(VEL_THREADS),
                                    0, st, w->S, V);
             }
-            if (w->timing) HIP_TRY(hipEventRecord(e1, st));
+            if (timed) timing_end(w, st);
             LAUNCH_BY_LANES(rem2d_post_kernel);
         } else {
-            if (w->timing) HIP_TRY(hipEventRecord(e0, st));
+            timed = timing_begin(w, st);
             // 3 waves/SIMD only when the grid can fill them (> 2 waves per SIMD on 256 CUs x 4 SIMDs)
             static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
             const bool three = forced ? forced == 3 : grid.x > 2u * 1024u * 2u;
@@ -422,9 +602,8 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
             default: LAUNCH_STEP(64); break;
             }
 #undef LAUNCH_STEP
-            if (w->timing) HIP_TRY(hipEventRecord(e1, st));
+            if (timed) timing_end(w, st);
         }
-        if (w->timing) w->pending.emplace_back(e0, e1);
         if (continuous) {
             LAUNCH_BY_LANES(rem2d_toi_scan_kernel);
             LAUNCH_BY_LANES(rem2d_toi_heavy_kernel);
@@ -462,6 +641,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     if (n_steps <= 0) return REM2D_OK;
     rem2d_world *w0 = ws[0];
     HIP_TRY(hipSetDevice(w0->cfg.device));
+    if (pipeline_mode() == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
     const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     StepArgs A;
     A.nSteps = continuous ? 1 : n_steps;
@@ -474,7 +654,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     // the merged kernel's 3-waves/SIMD build spills in every lane-count variant; 2 waves/SIMD measured faster
     static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
     const bool three = forced == 3;
-    static const bool split = getenv("REM2D_PIPELINE") && atoi(getenv("REM2D_PIPELINE")) == 1;
+    const bool split = pipeline_mode() == 1;
     if (split) A.nSteps = 1;
     VelBatch VB;
     memset(&VB, 0, sizeof(VB));
@@ -496,12 +676,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
             return fail(REM2D_E_INVALID, "worlds of one launch must share the terrain friction");
     const int launches = (continuous || split) ? n_steps : 1;
     for (int l = 0; l < launches; ++l) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (w0->timing) {
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, st));
-        }
+        const bool timed = timing_begin(w0, st);
         if (split) {
             hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
             hipLaunchKernelGGL(rem2d_vel_multi_kernel, dim3(vblocks), dim3(VEL_THREADS), 0, st, VB, V);
@@ -511,10 +686,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
         } else {
             hipLaunchKernelGGL(rem2d_step_multi_kernel<2>, grid, block, 0, st, B, A);
         }
-        if (w0->timing) {
-            HIP_TRY(hipEventRecord(e1, st));
-            w0->pending.emplace_back(e0, e1);
-        }
+        if (timed) timing_end(w0, st);
         if (continuous) {
             hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
             hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
@@ -556,6 +728,21 @@ extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *of
 
 extern "C" int rem2d_world_enable_timing(rem2d_world *w, int32_t on) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    if (on) {
+        drain_timing(w);
+        const size_t want = on > 1 ? (size_t)on : 4096; // launches that can be timed before the next read-back
+        while (w->evPool.size() < want) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(hipEventCreate(&a));
+            hipError_t e = hipEventCreate(&b);
+            if (e != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return fail(REM2D_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+            }
+            w->evPool.emplace_back(a, b);
+        }
+    }
     w->timing = on != 0;
     return REM2D_OK;
 }

@@ -42,6 +42,13 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     const int sub = lane & (K - 1);
     const unsigned Lp = S.Lp;
     if (gl == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // evaluate() has left its loop for every creature of this wavefront
+        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) {
+            const unsigned mb = (unsigned)SCR_MISC_BASE * Lp + gl;
+            SW(mb, 0) = __int_as_float(0); // nothing to solve for the velocity kernel; post and the TOI kernels skip too
+            return;
+        }
+    }
 
     const int shape = LI(L_SHAPE);
     const bool active = shape != SHAPE_NONE;
@@ -583,6 +590,9 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
     const unsigned Lp = S.Lp;
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) {
+        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return; // pre skipped this wavefront too
+    }
 
     const int shape = LI(L_SHAPE);
     const bool active = shape != SHAPE_NONE;

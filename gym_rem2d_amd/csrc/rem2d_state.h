@@ -80,6 +80,7 @@ struct State {
     char *lane4, *lane8, *slot4, *env4, *env8; // group bases inside the caller's arena
     float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
     int *toiWork;                              // handle-owned: [0] count, [16..16+Lp) bodies that need the full TOI solve
+    const int *tiles;                          // handle-owned: tile t of the velocity kernel = creatures [tiles[t], tiles[t+1])
     unsigned Lp, Np, nEnvs, flags;
 };
 // accessors (S, gl and env must be in scope where they are used)

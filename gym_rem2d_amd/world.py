@@ -73,6 +73,11 @@ class BatchedWorld:
             setattr(m, k, dev[k].data_ptr())
         self._morph_dev = dev  # keep alive until the reset kernel has run
         _lib.check(_lib.lib().rem2d_world_reset(self.h, C.byref(m), self._stream()))
+        # work partition of the velocity kernel: consecutive creatures packed into tiles of <= 256 lanes with <= 64
+        # joints per schedule phase (include/rem2d.h, rem2d_world_set_tiles)
+        self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
+                                     self.n_envs_padded)
+        _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def step(self, n_steps=1):
         _lib.check(_lib.lib().rem2d_world_step(self.h, int(n_steps), self._stream()))

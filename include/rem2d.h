@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 2 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem */
+#define REM2D_ABI_VERSION 3 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles */
 
 enum {
     REM2D_OK = 0,
@@ -132,6 +132,23 @@ int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, in
  * robots (create_robot :517-563) from the uploaded layout; wall of death back to 0. */
 int rem2d_world_reset(rem2d_world *w, const rem2d_morph *morph_dev, void *stream);
 
+/* Work partition of the velocity kernel (no counterpart in the reference: Box2D walks one island at a time,
+ * b2World::Solve).  The 180 velocity iterations of world.Step (Modular2DEnv.py:634) run one TILE per wavefront: tile t
+ * = creatures [tile_start[t], tile_start[t+1]).  Rules, checked here or flagged as REM2D_ERR_SOLVER_OVERFLOW by the
+ * kernel: tile_start[0] = 0, strictly increasing, tile_start[n_tiles] in [n_envs, padded envs]; at most 256 lanes per
+ * tile; at most 64 joints per schedule phase (joint round mod the tile's largest pipeline period) per tile.  Optional:
+ * rem2d_world_create installs a valid default (128 / lanes creatures per tile); a host that knows the morphologies
+ * packs tighter (gym_rem2d_amd.compiler.Morphology.tiles).  HOST pointer, copied. */
+int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_tiles);
+/* Greedy tile plan from a morphology batch (HOST arrays in the layout of rem2d_morph: parent[n_envs*lanes],
+ * jround[n_envs*lanes] = round | contact slot << 8 | period << 16).  Consecutive creatures are packed into a tile while
+ * it stays within 256 lanes, 64 joints per schedule phase and max_creatures creatures (0: the default, 32 -- keeps the
+ * tile's touching manifolds within the 128 that rem2d_vel4_kernel holds in registers for typical morphologies).
+ * n_padded >= n_envs: creatures [n_envs, n_padded) are empty padding (rem2d_padded_envs).  tile_start_out needs room
+ * for n_padded + 1 entries; *n_tiles_out receives the tile count. */
+int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
+                     int32_t max_creatures, int32_t *tile_start_out, int32_t *n_tiles_out);
+
 /* n_steps x Modular2D.step (Modular2DEnv.py:607-653): wod.update, controller sweep
  * (m_controller.py:17-21), PID -> joint.motorSpeed (:600-605,:631-632),
  * world.Step(1/50, 180, 60) (:634), reward / done (:642-649) and evaluate()'s fitness rule
@@ -192,6 +209,8 @@ int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes,
 /* Average device time of the step kernel over the launches since the last call, measured
  * with HIP events on the launch stream (bench.py's roofline leg).  Synchronises. */
 int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int64_t *launches);
+/* on = 0: off; on = 1: on, room for 4096 timed launches between two read-backs; on > 1: room for `on` launches.  The
+ * event pairs are created here, not inside the step calls. */
 int rem2d_world_enable_timing(rem2d_world *w, int32_t on);
 
 #ifdef __cplusplus

@@ -12,10 +12,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librem2d_oracle.so")
+_SO_F64 = os.path.join(_HERE, "librem2d_oracle_f64.so")   # binary64 "truth" build of the same source
 
 FLAG_CONTINUOUS = 1
 FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
+FLAG_TOI_TRANSPARENT_STATICS = 8
 
 MORPH_F32 = ("hx", "hy", "x", "y", "angle", "ax", "ay", "bx", "by", "torque", "lower", "upper")
 MORPH_F64 = ("amp", "phase", "freq", "offset", "istate")
@@ -33,14 +35,28 @@ class OMorph(C.Structure):
 
 def build(force=False):
     """Compile the C restatement (gcc).  Building the checker is not using it."""
-    src = os.path.join(_HERE, "rem2d_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "librem2d_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+    src = [os.path.join(_HERE, "rem2d_oracle.c"), os.path.join(_HERE, "rem2d_oracle.h")]
+    newest = max(os.path.getmtime(f) for f in src)
+    for so in (_SO, _SO_F64):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
     return _SO
 
 
 _lib = None
+_lib_f64 = None
+
+
+def lib_f64():
+    """The binary64 build (every engine quantity a double; same ABI).  Not bit-comparable with anything: it measures
+    how much of a trajectory difference is inherent to binary32 (SURVEY.md 8c protocol iv)."""
+    global _lib_f64
+    if _lib_f64 is None:
+        if not os.path.exists(_SO_F64):
+            build()
+        _lib_f64 = _load(_SO_F64)
+        assert _lib_f64.rem2d_oracle_is_f64() == 1
+    return _lib_f64
 
 
 def lib():
@@ -48,7 +64,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
+        _lib = _load(_SO)
+    return _lib
+
+
+def _load(path):
+    if True:   # (indentation kept: the block below configures one CDLL instance)
+        L = C.CDLL(path)
         L.rem2d_oracle_terrain_create.restype = C.c_void_p
         L.rem2d_oracle_terrain_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float]
         L.rem2d_oracle_terrain_destroy.argtypes = [C.c_void_p]
@@ -65,7 +87,8 @@ def lib():
         L.rem2d_oracle_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         L.rem2d_oracle_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rem2d_oracle_env_step_ex.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        for f in ("num_bodies", "num_joints", "position_iterations", "toi_events"):
+        L.rem2d_oracle_batch_toi_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("num_bodies", "num_joints", "position_iterations", "toi_events", "toi_dynamic_advances"):
             getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p]
         for f in ("get_bodies", "get_mass", "get_joints"):
             getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p, C.c_void_p]
@@ -78,11 +101,15 @@ def lib():
         L.rem2d_oracle_sin.argtypes = [C.c_double]
         L.rem2d_oracle_box_mass.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.rem2d_oracle_circle_mass.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_is_f64.restype = C.c_int
+        for f in ("kat_distance", "kat_collide"):
+            getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p] * (5 if f == "kat_distance" else 6)
+        L.rem2d_oracle_kat_toi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.rem2d_oracle_kat_contact_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.rem2d_oracle_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 5
         L.rem2d_oracle_world_from_morph.restype = C.c_void_p
         L.rem2d_oracle_world_from_morph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
-        _lib = L
-    return _lib
+    return L
 
 
 def _ptr(a):
@@ -92,16 +119,17 @@ def _ptr(a):
 class Terrain:
     """Static terrain: npts heights -> npts-1 edge bodies (+ hardcore boxes)."""
 
-    def __init__(self, xs, ys, polys=None, friction=2.5):
+    def __init__(self, xs, ys, polys=None, friction=2.5, f64=False):
         self.xs = np.ascontiguousarray(xs, dtype=np.float32)
         self.ys = np.ascontiguousarray(ys, dtype=np.float32)
         self.polys = np.ascontiguousarray(polys if polys is not None else np.zeros((0, 4, 2)), dtype=np.float32)
-        self.h = lib().rem2d_oracle_terrain_create(_ptr(self.xs), _ptr(self.ys), len(self.xs),
-                                                   _ptr(self.polys), len(self.polys), friction)
+        self.L = lib_f64() if f64 else lib()   # a terrain belongs to the build that created it
+        self.h = self.L.rem2d_oracle_terrain_create(_ptr(self.xs), _ptr(self.ys), len(self.xs),
+                                                    _ptr(self.polys), len(self.polys), friction)
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().rem2d_oracle_terrain_destroy(self.h)
+            self.L.rem2d_oracle_terrain_destroy(self.h)
             self.h = None
 
 
@@ -226,6 +254,74 @@ class World:
     def toi_events(self):
         return lib().rem2d_oracle_toi_events(self.h)
 
+    @property
+    def toi_dynamic_advances(self):
+        return lib().rem2d_oracle_toi_dynamic_advances(self.h)
+
+
+# ---- standalone pieces for the known-answer tests ----
+TOI_STATES = ("unknown", "failed", "overlapped", "touching", "separated")
+
+
+def _spec(shape):
+    """("edge", x1, y1, x2, y2) | ("box", hx, hy) | ("circle", r) | ("poly", [(x, y), ...]) -> float32 spec."""
+    kind = shape[0]
+    if kind == "edge":
+        v = [0.0] + list(shape[1:5])
+    elif kind == "box":
+        v = [1.0, shape[1], shape[2]]
+    elif kind == "circle":
+        v = [2.0, shape[1]]
+    else:
+        pts = shape[1]
+        v = [3.0, float(len(pts))] + [c for p in pts for c in p]
+    return np.asarray(v, dtype=np.float32)
+
+
+def distance(shapeA, xfA, shapeB, xfB):
+    """b2Distance (useRadii=False) -> (pointA, pointB, distance, iterations); xf = (x, y, angle)."""
+    out = np.zeros(6, dtype=np.float32)
+    a, b = _spec(shapeA), _spec(shapeB)
+    xa, xb = np.asarray(xfA, dtype=np.float32), np.asarray(xfB, dtype=np.float32)
+    assert lib().rem2d_oracle_kat_distance(_ptr(a), _ptr(xa), _ptr(b), _ptr(xb), _ptr(out)) == 0
+    return out[0:2].copy(), out[2:4].copy(), float(out[4]), int(out[5])
+
+
+def time_of_impact(shapeA, sweepA, shapeB, sweepB, t_max=1.0):
+    """b2TimeOfImpact -> (state name, t); sweep = (c0x, c0y, a0, cx, cy, a)."""
+    out = np.zeros(2, dtype=np.float32)
+    a, b = _spec(shapeA), _spec(shapeB)
+    sa, sb = np.asarray(sweepA, dtype=np.float32), np.asarray(sweepB, dtype=np.float32)
+    assert lib().rem2d_oracle_kat_toi(_ptr(a), _ptr(sa), _ptr(b), _ptr(sb), t_max, _ptr(out)) == 0
+    return TOI_STATES[int(out[0])], float(out[1])
+
+
+def collide(shapeA, xfA, shapeB, xfB):
+    """narrowphase -> dict(type, count, keys, normal, point, points) in manifold-local coordinates."""
+    io, fo = np.zeros(4, dtype=np.int32), np.zeros(8, dtype=np.float32)
+    a, b = _spec(shapeA), _spec(shapeB)
+    xa, xb = np.asarray(xfA, dtype=np.float32), np.asarray(xfB, dtype=np.float32)
+    assert lib().rem2d_oracle_kat_collide(_ptr(a), _ptr(xa), _ptr(b), _ptr(xb), _ptr(io), _ptr(fo)) == 0
+    return dict(type=int(io[0]), count=int(io[1]), keys=(int(io[2]) & 0xffffffff, int(io[3]) & 0xffffffff),
+                normal=fo[0:2].copy(), point=fo[2:4].copy(), points=fo[4:8].reshape(2, 2).copy())
+
+
+def contact_solve(normal, points, cB, inv_mass, inv_I, friction, vB, wB, n_imp=(0.0, 0.0), t_imp=(0.0, 0.0)):
+    """One SolveVelocityConstraints sweep of one static-vs-body contact -> (v, w, normalImpulses, tangentImpulses, count)."""
+    pts = list(points) + [(0.0, 0.0)] * (2 - len(points))
+    vin = np.asarray([normal[0], normal[1], len(points), pts[0][0], pts[0][1], pts[1][0], pts[1][1], cB[0], cB[1],
+                      inv_mass, inv_I, friction, vB[0], vB[1], wB, n_imp[0], n_imp[1], t_imp[0], t_imp[1]], dtype=np.float32)
+    out = np.zeros(8, dtype=np.float32)
+    assert lib().rem2d_oracle_kat_contact_solve(_ptr(vin), _ptr(out)) == 0
+    return out[0:2].copy(), float(out[2]), out[3:5].copy(), out[5:7].copy(), int(out[7])
+
+
+def batch_toi_stats(reset=True):
+    """(TOI sub-steps, forced dynamic-sweep advances) over all batch_run worlds since the last reset."""
+    ev, adv = C.c_longlong(), C.c_longlong()
+    lib().rem2d_oracle_batch_toi_stats(C.byref(ev), C.byref(adv), 1 if reset else 0)
+    return ev.value, adv.value
+
 
 def sincosf(a):
     s = C.c_float()
@@ -263,7 +359,7 @@ def batch_run(terrain, m, n_steps, n_threads=1, flags=0, trace=False):
     done = np.zeros(N, dtype=np.int32)
     fitness = np.zeros(N, dtype=np.float64)
     tr = np.zeros((n_steps, N, K, 3), dtype=np.float32) if trace else None
-    rc = lib().rem2d_oracle_batch_run(terrain.h, C.byref(om), n_steps, n_threads, flags, _ptr(bodies),
+    rc = terrain.L.rem2d_oracle_batch_run(terrain.h, C.byref(om), n_steps, n_threads, flags, _ptr(bodies),
                                       _ptr(reward), _ptr(done), _ptr(fitness),
                                       _ptr(tr) if trace else None)
     if rc != 0:

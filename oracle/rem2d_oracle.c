@@ -30,7 +30,18 @@
 #include <omp.h>
 #endif
 
+/* REM2D_ORACLE_F64: the "truth" build (librem2d_oracle_f64.so).  Every engine quantity is binary64 (positions,
+ * velocities, impulses, manifolds, GJK / TOI), constants keep Box2D's binary32 literals, b2Rot::Set uses the binary64
+ * sine / cosine.  Same ABI (float arrays in and out; the conversion happens at the boundary).  It quantifies how much
+ * of a trajectory difference is inherent to binary32 arithmetic (SURVEY.md 8c protocol iv); it is NOT bit-comparable
+ * with anything. */
+#ifdef REM2D_ORACLE_F64
+typedef double f32;
+#define sqrtf sqrt
+#define floorf floor
+#else
 typedef float f32;
+#endif
 
 /* ---- A.1 constants (b2Settings.h) ---- */
 #define B2_PI 3.14159265359f
@@ -171,7 +182,14 @@ double rem2d_oracle_sin(double x) {
 }
 static inline rot_t rot_set(f32 a) {
     rot_t q;
+#ifdef REM2D_ORACLE_F64
+    double ds, dc;
+    o_sincos_d(a, &ds, &dc);
+    q.s = ds;
+    q.c = dc;
+#else
     rem2d_oracle_sincosf(a, &q.s, &q.c);
+#endif
     return q;
 }
 
@@ -455,6 +473,7 @@ typedef struct {
 } contact_t;
 
 #define O_MAX_CONTACTS (O_MAX_BODIES * O_MAX_BODY_CONTACTS)
+#define O_MAX_STATICS 512
 
 typedef struct { v2 c; f32 a; } pos_t;
 typedef struct { v2 v; f32 w; } vel_t;
@@ -475,6 +494,11 @@ struct o_world {
     int islandJointCount, islandJoints[O_MAX_BODIES];
     int lastPositionIterations;
     int toiEvents;
+    /* b2World::SolveTOI bookkeeping on the static (terrain) bodies: every terrain edge / hardcore box is its
+     * own b2Body, so each carries m_sweep.alpha0 and e_islandFlag (A.8) */
+    f32 staticAlpha0[O_MAX_STATICS];
+    unsigned char staticIslandFlag[O_MAX_STATICS];
+    int toiDynamicAdvances; /* times a static's alpha0 forced bB->m_sweep.Advance (provably never) */
     /* Modular2D state */
     double wod;
     int overflow;
@@ -1280,6 +1304,53 @@ static void contact_solver_setup(o_world *w, island_t *is, const step_t *step) {
         }
     }
 }
+/* the per-point / per-contact effective masses of b2ContactSolver::InitializeVelocityConstraints, from the world
+ * manifold points (shared with the known-answer entry point rem2d_oracle_kat_contact_solve) */
+static void vc_init_masses(vc_t *vc, const v2 *wmPoints, v2 cA, v2 cB, v2 vA, f32 wA, v2 vB, f32 wB) {
+    f32 mA = vc->invMassA, mB = vc->invMassB, iA = vc->invIA, iB = vc->invIB;
+    int pointCount = vc->pointCount;
+    for (int j = 0; j < pointCount; ++j) {
+        vcp_t *vcp = &vc->points[j];
+        vcp->rA = vsub(wmPoints[j], cA);
+        vcp->rB = vsub(wmPoints[j], cB);
+        f32 rnA = vcross(vcp->rA, vc->normal);
+        f32 rnB = vcross(vcp->rB, vc->normal);
+        f32 kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        vcp->normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+        v2 tangent = vcross_vs(vc->normal, 1.0f);
+        f32 rtA = vcross(vcp->rA, tangent);
+        f32 rtB = vcross(vcp->rB, tangent);
+        f32 kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+        vcp->tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+        vcp->velocityBias = 0.0f;
+        f32 vRel = vdot(vc->normal,
+                        vsub(vsub(vadd(vB, vcross_sv(wB, vcp->rB)), vA), vcross_sv(wA, vcp->rA)));
+        if (vRel < -B2_VELOCITY_THRESHOLD) vcp->velocityBias = -vc->restitution * vRel;
+    }
+    if (vc->pointCount == 2) {
+        vcp_t *vcp1 = &vc->points[0], *vcp2 = &vc->points[1];
+        f32 rn1A = vcross(vcp1->rA, vc->normal);
+        f32 rn1B = vcross(vcp1->rB, vc->normal);
+        f32 rn2A = vcross(vcp2->rA, vc->normal);
+        f32 rn2B = vcross(vcp2->rB, vc->normal);
+        f32 k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+        f32 k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+        f32 k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+        const f32 k_maxConditionNumber = 1000.0f;
+        if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
+            vc->K_exx = k11; vc->K_exy = k12; vc->K_eyx = k12; vc->K_eyy = k22;
+            f32 a = vc->K_exx, b = vc->K_eyx, c = vc->K_exy, d = vc->K_eyy;
+            f32 det = a * d - b * c;
+            if (det != 0.0f) det = 1.0f / det;
+            vc->nm_exx = det * d;
+            vc->nm_eyx = -det * b;
+            vc->nm_exy = -det * c;
+            vc->nm_eyy = det * a;
+        } else {
+            vc->pointCount = 1;
+        }
+    }
+}
 static void contact_solver_init_velocity(o_world *w, island_t *is) {
     for (int i = 0; i < is->ncontact; ++i) {
         vc_t *vc = &is->vcs[i];
@@ -1287,7 +1358,6 @@ static void contact_solver_init_velocity(o_world *w, island_t *is) {
         f32 radiusA = pc->radiusA, radiusB = pc->radiusB;
         const manifold_t *manifold = &w->contacts[vc->contactIndex].m;
         int indexA = vc->indexA, indexB = vc->indexB;
-        f32 mA = vc->invMassA, mB = vc->invMassB, iA = vc->invIA, iB = vc->invIB;
         v2 localCenterA = pc->localCenterA, localCenterB = pc->localCenterB;
         v2 cA = is->positions[indexA].c;
         f32 aA = is->positions[indexA].a;
@@ -1306,48 +1376,7 @@ static void contact_solver_init_velocity(o_world *w, island_t *is) {
         v2 wmNormal = V2(0.0f, 0.0f);
         world_manifold(manifold, xfA, radiusA, xfB, radiusB, &wmNormal, wmPoints);
         vc->normal = wmNormal;
-        int pointCount = vc->pointCount;
-        for (int j = 0; j < pointCount; ++j) {
-            vcp_t *vcp = &vc->points[j];
-            vcp->rA = vsub(wmPoints[j], cA);
-            vcp->rB = vsub(wmPoints[j], cB);
-            f32 rnA = vcross(vcp->rA, vc->normal);
-            f32 rnB = vcross(vcp->rB, vc->normal);
-            f32 kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-            vcp->normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-            v2 tangent = vcross_vs(vc->normal, 1.0f);
-            f32 rtA = vcross(vcp->rA, tangent);
-            f32 rtB = vcross(vcp->rB, tangent);
-            f32 kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
-            vcp->tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-            vcp->velocityBias = 0.0f;
-            f32 vRel = vdot(vc->normal,
-                            vsub(vsub(vadd(vB, vcross_sv(wB, vcp->rB)), vA), vcross_sv(wA, vcp->rA)));
-            if (vRel < -B2_VELOCITY_THRESHOLD) vcp->velocityBias = -vc->restitution * vRel;
-        }
-        if (vc->pointCount == 2) {
-            vcp_t *vcp1 = &vc->points[0], *vcp2 = &vc->points[1];
-            f32 rn1A = vcross(vcp1->rA, vc->normal);
-            f32 rn1B = vcross(vcp1->rB, vc->normal);
-            f32 rn2A = vcross(vcp2->rA, vc->normal);
-            f32 rn2B = vcross(vcp2->rB, vc->normal);
-            f32 k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
-            f32 k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
-            f32 k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
-            const f32 k_maxConditionNumber = 1000.0f;
-            if (k11 * k11 < k_maxConditionNumber * (k11 * k22 - k12 * k12)) {
-                vc->K_exx = k11; vc->K_exy = k12; vc->K_eyx = k12; vc->K_eyy = k22;
-                f32 a = vc->K_exx, b = vc->K_eyx, c = vc->K_exy, d = vc->K_eyy;
-                f32 det = a * d - b * c;
-                if (det != 0.0f) det = 1.0f / det;
-                vc->nm_exx = det * d;
-                vc->nm_eyx = -det * b;
-                vc->nm_exy = -det * c;
-                vc->nm_eyy = det * a;
-            } else {
-                vc->pointCount = 1;
-            }
-        }
+        vc_init_masses(vc, wmPoints, cA, cB, vA, wA, vB, wB);
     }
 }
 static void contact_solver_warm_start(island_t *is) {
@@ -1833,6 +1862,34 @@ static void body_sync_fixtures(o_world *w, int bi) {
 }
 
 /* ---- A.4 b2Island::Solve ---- */
+
+#ifdef REM2D_ORACLE_PROBE
+/* Diagnostic build only (tools/probe_fixed_point.py): at which velocity iteration does a sweep stop changing any
+ * bit of the solver state?  From there on every further sweep is a no-op. */
+static int g_probe_hist[512];
+static _Thread_local f32 t_probe[2][8 * O_MAX_BODIES + 4 * O_MAX_CONTACTS];
+static int probe_snapshot(o_world *w, island_t *is, int which) {
+    f32 *o = t_probe[which];
+    int n = 0;
+    for (int i = 0; i < is->nbody; ++i) { o[n++] = is->velocities[i].v.x; o[n++] = is->velocities[i].v.y; o[n++] = is->velocities[i].w; }
+    for (int i = 0; i < is->njoint; ++i) {
+        joint_t *j = &w->joints[is->joints[i]];
+        o[n++] = j->impulse.x; o[n++] = j->impulse.y; o[n++] = j->impulse.z; o[n++] = j->motorImpulse;
+    }
+    for (int i = 0; i < is->ncontact; ++i)
+        for (int k = 0; k < is->vcs[i].pointCount; ++k) { o[n++] = is->vcs[i].points[k].normalImpulse; o[n++] = is->vcs[i].points[k].tangentImpulse; }
+    return which == 1 && memcmp(t_probe[0], t_probe[1], (size_t)n * sizeof(f32)) == 0;
+}
+static void probe_record(int it, int maxIt) {
+    (void)maxIt;
+    if (it > 511) it = 511;
+    __atomic_fetch_add(&g_probe_hist[it], 1, __ATOMIC_RELAXED);
+}
+void rem2d_oracle_probe_hist(int *out, int reset) {
+    for (int i = 0; i < 512; ++i) { out[i] = g_probe_hist[i]; if (reset) g_probe_hist[i] = 0; }
+}
+#endif
+
 static void island_solve(o_world *w, island_t *is, const step_t *step) {
     f32 h = step->dt;
     is->positions[IDX_STATIC].c = V2(0.0f, 0.0f);
@@ -1863,8 +1920,15 @@ static void island_solve(o_world *w, island_t *is, const step_t *step) {
     if (step->warmStarting) contact_solver_warm_start(is);
     for (int i = 0; i < is->njoint; ++i) joint_init_velocity(w, is, &w->joints[is->joints[i]], step);
     for (int it = 0; it < step->velocityIterations; ++it) {
+#ifdef REM2D_ORACLE_PROBE
+        probe_snapshot(w, is, 0);
+#endif
         for (int i = 0; i < is->njoint; ++i) joint_solve_velocity(is, &w->joints[is->joints[i]], step);
         contact_solver_solve_velocity(is);
+#ifdef REM2D_ORACLE_PROBE
+        if (probe_snapshot(w, is, 1)) { probe_record(it, step->velocityIterations); break; } /* fixed point: later sweeps are no-ops */
+        if (it + 1 == step->velocityIterations) probe_record(it + 1, step->velocityIterations);
+#endif
     }
     contact_solver_store(w, is);
     for (int i = 0; i < is->nbody; ++i) {
@@ -2615,14 +2679,27 @@ static void island_solve_toi(o_world *w, island_t *is, const step_t *subStep, in
         body_sync_transform(b);
     }
 }
-/* b2World::SolveTOI.  Every contact on this path is (static A, dynamic non-bullet B). */
+/* b2Sweep::Advance on a static terrain body: c0 == c and a0 == a (the body never moves), so
+ * c0 += beta * (c - c0) leaves the pose bit-identical and only alpha0 changes. */
+static void static_advance(o_world *w, int s, f32 alpha) { w->staticAlpha0[s] = alpha; }
+
+/* b2World::SolveTOI.  Every contact on this path is (static A, dynamic non-bullet B).  Each terrain edge /
+ * hardcore box is its own static b2Body (Modular2DEnv.py:294-306, 217-275), so the sweep.alpha0 / e_islandFlag
+ * bookkeeping Box2D does on body A is modelled per static (O_FLAG_TOI_TRANSPARENT_STATICS switches it off: the
+ * round-1 form, kept to show that both give the same bits -- DESIGN.md section 2 has the argument). */
 static void world_solve_toi(o_world *w, const step_t *step) {
     static _Thread_local island_t island;
     island_t *is = &island;
+    const int bookkeeping = (w->flags & O_FLAG_TOI_TRANSPARENT_STATICS) == 0;
+    const int nstatic = w->terrain->nstatic;
     if (w->stepComplete) {
         for (int i = 0; i < w->nbody; ++i) {
             w->bodies[i].islandFlag = 0;
             w->bodies[i].alpha0 = 0.0f;
+        }
+        for (int s = 0; s < nstatic; ++s) { /* the static bodies are in m_bodyList too */
+            w->staticIslandFlag[s] = 0;
+            w->staticAlpha0[s] = 0.0f;
         }
         for (int k = 0; k < w->wcount; ++k) {
             contact_t *c = &w->contacts[w->wlist[k]];
@@ -2647,8 +2724,19 @@ static void world_solve_toi(o_world *w, const step_t *step) {
                 int activeB = bB->awake;
                 if (!activeB) continue; /* static A is never active */
                 /* collideA = bulletA || typeB != dynamic = false; collideB = typeA != dynamic = true */
-                f32 alpha0 = bB->alpha0; /* static alpha0 = 0 <= alpha0 of B; advance A (no-op) */
-                if (0.0f > alpha0) alpha0 = 0.0f;
+                /* Put the sweeps onto the same time interval. */
+                f32 alphaA = bookkeeping ? w->staticAlpha0[c->staticIdx] : 0.0f;
+                f32 alpha0 = alphaA;
+                if (alphaA < bB->alpha0) {
+                    alpha0 = bB->alpha0;
+                    if (bookkeeping) static_advance(w, c->staticIdx, alpha0); /* bA->m_sweep.Advance(alpha0) */
+                } else if (bB->alpha0 < alphaA) {
+                    alpha0 = alphaA;
+                    sweep_t sb = body_sweep(bB);
+                    sweep_advance(&sb, alpha0); /* bB->m_sweep.Advance(alpha0): moves c0 / a0 of B */
+                    body_set_sweep(bB, &sb);
+                    w->toiDynamicAdvances++;
+                }
                 proxy_t pA, pB;
                 proxy_set(&pA, &w->terrain->statics[c->staticIdx].shape);
                 proxy_set(&pB, &bB->shape);
@@ -2677,13 +2765,17 @@ static void world_solve_toi(o_world *w, const step_t *step) {
         contact_t *mc = &w->contacts[minContact];
         int bBi = mc->body;
         body_t *bB = &w->bodies[bBi];
+        const int sA0 = mc->staticIdx;
+        f32 backup1 = w->staticAlpha0[sA0]; /* b2Sweep backup1 = bA->m_sweep (only alpha0 can differ) */
         sweep_t backup2 = body_sweep(bB);
+        if (bookkeeping) static_advance(w, sA0, minAlpha); /* bA->Advance(minAlpha) */
         body_advance(bB, minAlpha);
         contact_update(w, mc);
         mc->toiFlag = 0;
         ++mc->toiCount;
         if (!mc->enabled || !mc->touching) {
             mc->enabled = 0;
+            w->staticAlpha0[sA0] = backup1;
             body_set_sweep(bB, &backup2);
             body_sync_transform(bB);
             continue;
@@ -2697,18 +2789,30 @@ static void world_solve_toi(o_world *w, const step_t *step) {
         is->contacts[is->ncontact++] = minContact;
         bB->islandFlag = 1;
         mc->islandFlag = 1;
+        int islandStatics[B2_MAX_TOI_CONTACTS + 1], nIslandStatics = 0;
+        w->staticIslandFlag[sA0] = 1;
+        islandStatics[nIslandStatics++] = sA0;
+        /* bodies[2] = {bA, bB}: bA is static (m_type != b2_dynamicBody), only bB's contact list is walked */
         for (int k = 0; k < bB->ncontacts; ++k) {
+            /* island.m_bodyCapacity = 2 * b2_maxTOIContacts is never reached before the contact capacity:
+             * every static added below comes with a contact */
             if (is->ncontact == B2_MAX_TOI_CONTACTS) break;
             int ci = bB->contacts[k];
             contact_t *c = &w->contacts[ci];
             if (c->islandFlag) continue;
             /* other is static: always allowed (only dynamic non-bullet others are skipped) */
-            /* Tentatively advance the body to the TOI: other is static, nothing to advance */
+            const int so = c->staticIdx;
+            /* Tentatively advance the body to the TOI. */
+            f32 backup = w->staticAlpha0[so];
+            if (bookkeeping && !w->staticIslandFlag[so]) static_advance(w, so, minAlpha);
             contact_update(w, c);
-            if (!c->enabled) continue;
-            if (!c->touching) continue;
+            if (!c->enabled) { w->staticAlpha0[so] = backup; continue; }
+            if (!c->touching) { w->staticAlpha0[so] = backup; continue; }
             c->islandFlag = 1;
             is->contacts[is->ncontact++] = ci;
+            if (w->staticIslandFlag[so]) continue;
+            w->staticIslandFlag[so] = 1; /* other->SetAwake is skipped for static bodies */
+            islandStatics[nIslandStatics++] = so;
         }
         step_t subStep;
         subStep.dt = (1.0f - minAlpha) * step->dt;
@@ -2718,6 +2822,7 @@ static void world_solve_toi(o_world *w, const step_t *step) {
         subStep.velocityIterations = step->velocityIterations;
         subStep.warmStarting = 0;
         island_solve_toi(w, is, &subStep, 0);
+        for (int i = 0; i < nIslandStatics; ++i) w->staticIslandFlag[islandStatics[i]] = 0;
         for (int i = 0; i < is->nbody; ++i) {
             body_t *b = &w->bodies[is->bodies[i]];
             b->islandFlag = 0;
@@ -2854,16 +2959,156 @@ void rem2d_oracle_get_fat_aabb(const o_world *w, int body, float *out) {
 }
 int rem2d_oracle_position_iterations(const o_world *w) { return w->lastPositionIterations; }
 int rem2d_oracle_toi_events(const o_world *w) { return w->toiEvents; }
+int rem2d_oracle_toi_dynamic_advances(const o_world *w) { return w->toiDynamicAdvances; }
 
+int rem2d_oracle_is_f64(void) { return (int)(sizeof(f32) == 8); }
 void rem2d_oracle_box_mass(float hx, float hy, float *mass, float *I) {
     shape_t s;
     shape_set_box(&s, hx, hy);
     v2 c;
-    poly_mass(&s, 1.0f, mass, &c, I);
+    f32 m, i;
+    poly_mass(&s, 1.0f, &m, &c, &i);
+    *mass = (float)m;
+    *I = (float)i;
 }
-void rem2d_oracle_circle_mass(float r, float *mass, float *I) { circle_mass(r, V2(0.0f, 0.0f), 1.0f, mass, I); }
+void rem2d_oracle_circle_mass(float r, float *mass, float *I) {
+    f32 m, i;
+    circle_mass(r, V2(0.0f, 0.0f), 1.0f, &m, &i);
+    *mass = (float)m;
+    *I = (float)i;
+}
+
+/* ---- standalone entry points for the known-answer tests (tests/test_oracle_kat.py) ---- */
+/* shape spec: {0, x1, y1, x2, y2} edge | {1, hx, hy} box | {2, r} circle | {3, n, x0, y0, ...} convex polygon */
+static int kat_shape(shape_t *s, const float *spec) {
+    int type = (int)spec[0];
+    memset(s, 0, sizeof(*s));
+    if (type == 0) {
+        s->type = SH_EDGE;
+        s->radius = B2_POLYGON_RADIUS;
+        s->v1 = V2(spec[1], spec[2]);
+        s->v2_ = V2(spec[3], spec[4]);
+    } else if (type == 1) {
+        shape_set_box(s, spec[1], spec[2]);
+    } else if (type == 2) {
+        s->type = SH_CIRCLE;
+        s->radius = spec[1];
+        s->p = V2(0.0f, 0.0f);
+    } else if (type == 3) {
+        int n = (int)spec[1];
+        v2 vs[B2_MAX_POLY];
+        if (n < 3 || n > B2_MAX_POLY) return -1;
+        for (int i = 0; i < n; ++i) vs[i] = V2(spec[2 + 2 * i], spec[3 + 2 * i]);
+        if (shape_set_poly(s, vs, n) != 0) return -1;
+    } else return -1;
+    return 0;
+}
+static xf_t kat_xf(const float *x) {
+    xf_t t;
+    t.p = V2(x[0], x[1]);
+    t.q = rot_set(x[2]);
+    return t;
+}
+/* b2Distance (useRadii = false): out = pointA.xy pointB.xy distance iterations */
+int rem2d_oracle_kat_distance(const float *specA, const float *xfA, const float *specB, const float *xfB, float *out) {
+    shape_t a, b;
+    if (kat_shape(&a, specA) || kat_shape(&b, specB)) return -1;
+    proxy_t pa, pb;
+    proxy_set(&pa, &a);
+    proxy_set(&pb, &b);
+    simplex_cache_t cache;
+    memset(&cache, 0, sizeof(cache));
+    dist_out_t d;
+    b2distance(&d, &cache, &pa, kat_xf(xfA), &pb, kat_xf(xfB));
+    out[0] = (float)d.pointA.x; out[1] = (float)d.pointA.y; out[2] = (float)d.pointB.x; out[3] = (float)d.pointB.y;
+    out[4] = (float)d.distance; out[5] = (float)d.iterations;
+    return 0;
+}
+/* b2TimeOfImpact: sweep = c0.xy a0 c.xy a (localCenter 0, alpha0 0); out = state (TOI_*), t */
+int rem2d_oracle_kat_toi(const float *specA, const float *sweepA, const float *specB, const float *sweepB, float tMax,
+                         float *out) {
+    shape_t a, b;
+    if (kat_shape(&a, specA) || kat_shape(&b, specB)) return -1;
+    proxy_t pa, pb;
+    proxy_set(&pa, &a);
+    proxy_set(&pb, &b);
+    sweep_t sa, sb;
+    memset(&sa, 0, sizeof(sa));
+    memset(&sb, 0, sizeof(sb));
+    sa.c0 = V2(sweepA[0], sweepA[1]); sa.a0 = sweepA[2]; sa.c = V2(sweepA[3], sweepA[4]); sa.a = sweepA[5];
+    sb.c0 = V2(sweepB[0], sweepB[1]); sb.a0 = sweepB[2]; sb.c = V2(sweepB[3], sweepB[4]); sb.a = sweepB[5];
+    int state;
+    f32 t;
+    time_of_impact(&state, &t, &pa, &sa, &pb, &sb, tMax);
+    out[0] = (float)state;
+    out[1] = (float)t;
+    return 0;
+}
+/* narrowphase dispatch of contact_evaluate; iout = type pointCount key0 key1; fout = localNormal.xy localPoint.xy
+ * p0.xy p1.xy */
+int rem2d_oracle_kat_collide(const float *specA, const float *xfA, const float *specB, const float *xfB, int32_t *iout,
+                             float *fout) {
+    shape_t a, b;
+    if (kat_shape(&a, specA) || kat_shape(&b, specB)) return -1;
+    manifold_t m;
+    memset(&m, 0, sizeof(m));
+    if (a.type == SH_EDGE && b.type == SH_POLY) collide_edge_polygon(&m, &a, kat_xf(xfA), &b, kat_xf(xfB));
+    else if (a.type == SH_EDGE && b.type == SH_CIRCLE) collide_edge_circle(&m, &a, kat_xf(xfA), &b, kat_xf(xfB));
+    else if (a.type == SH_POLY && b.type == SH_POLY) collide_polygons(&m, &a, kat_xf(xfA), &b, kat_xf(xfB));
+    else if (a.type == SH_POLY && b.type == SH_CIRCLE) collide_polygon_circle(&m, &a, kat_xf(xfA), &b, kat_xf(xfB));
+    else return -1;
+    iout[0] = m.type; iout[1] = m.pointCount; iout[2] = (int32_t)m.points[0].id.key; iout[3] = (int32_t)m.points[1].id.key;
+    fout[0] = (float)m.localNormal.x; fout[1] = (float)m.localNormal.y; fout[2] = (float)m.localPoint.x; fout[3] = (float)m.localPoint.y;
+    fout[4] = (float)m.points[0].localPoint.x; fout[5] = (float)m.points[0].localPoint.y;
+    fout[6] = (float)m.points[1].localPoint.x; fout[7] = (float)m.points[1].localPoint.y;
+    return 0;
+}
+/* One b2ContactSolver::SolveVelocityConstraints sweep over ONE contact between the static body (A) and a body B at
+ * cB: in = normal.xy, nPoints, p0.xy, p1.xy (world manifold points), cB.xy, invMassB, invIB, friction, vB.xy, wB,
+ * accumulated normalImpulse0/1, tangentImpulse0/1.  out = vB.xy wB normalImpulse0/1 tangentImpulse0/1 pointCount
+ * (the block solver may have dropped to one point). */
+int rem2d_oracle_kat_contact_solve(const float *in, float *out) {
+    static _Thread_local island_t island;
+    island_t *is = &island;
+    is->nbody = 1;
+    is->ncontact = 1;
+    is->njoint = 0;
+    vc_t *vc = &is->vcs[0];
+    memset(vc, 0, sizeof(*vc));
+    vc->normal = V2(in[0], in[1]);
+    vc->pointCount = (int)in[2];
+    v2 pts[2] = {V2(in[3], in[4]), V2(in[5], in[6])};
+    v2 cB = V2(in[7], in[8]);
+    vc->indexA = IDX_STATIC;
+    vc->indexB = 0;
+    vc->invMassA = 0.0f; vc->invIA = 0.0f;
+    vc->invMassB = in[9]; vc->invIB = in[10];
+    vc->friction = in[11];
+    is->velocities[IDX_STATIC].v = V2(0.0f, 0.0f);
+    is->velocities[IDX_STATIC].w = 0.0f;
+    is->velocities[0].v = V2(in[12], in[13]);
+    is->velocities[0].w = in[14];
+    vc_init_masses(vc, pts, V2(0.0f, 0.0f), cB, V2(0.0f, 0.0f), 0.0f, is->velocities[0].v, is->velocities[0].w);
+    vc->points[0].normalImpulse = in[15]; vc->points[1].normalImpulse = in[16];
+    vc->points[0].tangentImpulse = in[17]; vc->points[1].tangentImpulse = in[18];
+    contact_solver_solve_velocity(is);
+    out[0] = (float)is->velocities[0].v.x; out[1] = (float)is->velocities[0].v.y; out[2] = (float)is->velocities[0].w;
+    out[3] = (float)vc->points[0].normalImpulse; out[4] = (float)vc->points[1].normalImpulse;
+    out[5] = (float)vc->points[0].tangentImpulse; out[6] = (float)vc->points[1].tangentImpulse;
+    out[7] = (float)vc->pointCount;
+    return 0;
+}
 
 /* ---- batch driver ---- */
+static long long g_batchToiEvents, g_batchToiDynamicAdvances; /* summed over the worlds of rem2d_oracle_batch_run */
+void rem2d_oracle_batch_toi_stats(long long *events, long long *dynamic_advances, int reset) {
+    if (events) *events = __atomic_load_n(&g_batchToiEvents, __ATOMIC_RELAXED);
+    if (dynamic_advances) *dynamic_advances = __atomic_load_n(&g_batchToiDynamicAdvances, __ATOMIC_RELAXED);
+    if (reset) {
+        __atomic_store_n(&g_batchToiEvents, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&g_batchToiDynamicAdvances, 0, __ATOMIC_RELAXED);
+    }
+}
 o_world *rem2d_oracle_world_from_morph(const o_terrain *t, const o_morph *m, int e, unsigned flags) {
     o_world *w = rem2d_oracle_world_create(t, flags);
     int K = m->lanes;
@@ -2933,6 +3178,8 @@ int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, in
         if (reward_out) reward_out[e] = reward;
         if (done_out) done_out[e] = everDone;
         if (fitness_out) fitness_out[e] = fitness;
+        __atomic_fetch_add(&g_batchToiEvents, (long long)w->toiEvents, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_batchToiDynamicAdvances, (long long)w->toiDynamicAdvances, __ATOMIC_RELAXED);
         rem2d_oracle_world_destroy(w);
     }
     return 0;

@@ -28,6 +28,8 @@ extern "C" {
 #define O_FLAG_CONTINUOUS 1u         /* b2World continuousPhysics (SolveTOI), SURVEY A.8 */
 #define O_FLAG_SLEEP_RESET_ALWAYS 2u /* b2Body::SetAwake(true) always zeroes sleepTime (pre-2.3.1 variant) */
 #define O_FLAG_NO_SLEEP 4u           /* b2World(doSleep=False) */
+#define O_FLAG_TOI_TRANSPARENT_STATICS 8u /* SolveTOI without the static bodies' sweep.alpha0 / island-flag bookkeeping
+                                            * (round-1 form; bit-identical results, tests/test_oracle_kat.py) */
 
 #define O_MAX_BODIES 64
 #define O_MAX_BODY_CONTACTS 24
@@ -93,6 +95,8 @@ void rem2d_oracle_get_manifold(const o_world *, int body, int k, float *out);
 void rem2d_oracle_get_fat_aabb(const o_world *, int body, float *out);
 int rem2d_oracle_position_iterations(const o_world *); /* of last Solve */
 int rem2d_oracle_toi_events(const o_world *);          /* cumulative TOI sub-steps */
+/* times SolveTOI had to advance a dynamic body's sweep because its static partner's alpha0 was ahead */
+int rem2d_oracle_toi_dynamic_advances(const o_world *);
 
 /* standalone pieces for known-answer tests */
 void rem2d_oracle_sincosf(float a, float *s, float *c);
@@ -111,6 +115,10 @@ void rem2d_oracle_circle_mass(float r, float *mass, float *I);
 int rem2d_oracle_batch_run(const o_terrain *, const o_morph *, int n_steps, int n_threads,
                            unsigned flags, float *bodies_out, double *reward_out,
                            int32_t *done_out, double *fitness_out, float *trace_out);
+
+/* TOI sub-steps and forced dynamic-sweep advances (see rem2d_oracle_toi_dynamic_advances) summed over all worlds
+ * that rem2d_oracle_batch_run has stepped since the last reset. */
+void rem2d_oracle_batch_toi_stats(long long *events, long long *dynamic_advances, int reset);
 
 /* Build a single world from env `e` of a morphology batch. */
 o_world *rem2d_oracle_world_from_morph(const o_terrain *, const o_morph *, int e, unsigned flags);
