@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "librem2d.so")
+LIB_PATH = os.environ.get("REM2D_LIB_PATH") or os.path.join(_HERE, "librem2d.so")   # override: A/B builds on the GPU box
 SRC_PATH = os.path.join(_HERE, "csrc", "rem2d.hip")
 
 FLAG_CONTINUOUS = 1

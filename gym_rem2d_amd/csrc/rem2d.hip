@@ -109,6 +109,19 @@ struct rem2d_world {
     int evUsed;
 };
 
+// Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
+//   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
+//   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3)   2: the same at 5 waves/SIMD (spills)
+struct TileShape { int sets, passes, csets; };
+static int tile_shape_id() {
+    static const int id = getenv("REM2D_TILE_SHAPE") ? atoi(getenv("REM2D_TILE_SHAPE")) : 3;
+    return id < 0 || id > 3 ? 3 : id;
+}
+static TileShape tile_shape() {
+    static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}};
+    return shapes[tile_shape_id()];
+}
+
 extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
 extern "C" const char *rem2d_last_error(void) { return g_err.c_str(); }
 
@@ -180,7 +193,11 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     // are a matching of its tree (<= lanes / 2 of them), so such a tile never has more than 64 joints in a phase;
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
     {
-        const int per = cfg->lanes >= 128 ? 1 : (128 / cfg->lanes > 0 ? 128 / cfg->lanes : 1);
+        // (with one joint set per lane a tile holds at most 64 joints: 64 / lanes creatures)
+        const TileShape shp = tile_shape();
+        int per = (shp.sets >= 2 ? 128 : 64) / cfg->lanes;
+        if (per * cfg->lanes > shp.passes * WAVE) per = shp.passes * WAVE / cfg->lanes;
+        if (per < 1) per = 1;
         std::vector<int32_t> ts;
         for (int c = 0; c < L.Np; c += per) ts.push_back(c);
         ts.push_back(L.Np);
@@ -204,9 +221,8 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
     for (int t = 0; t < n_tiles; ++t) {
         const long long c = (long long)tile_start[t + 1] - tile_start[t];
         if (c <= 0) return fail(REM2D_E_INVALID, "tile starts must be strictly increasing");
-        if (c * w->cfg.lanes > V4_MAX_BODIES && c != 1) return fail(REM2D_E_INVALID, "a tile holds at most 256 bodies (lanes)");
+        if (c * w->cfg.lanes > tile_shape().passes * WAVE) return fail(REM2D_E_INVALID, "a tile holds too many lanes for the tile shape in use");
     }
-    if (w->cfg.lanes > V4_MAX_BODIES) return fail(REM2D_E_INVALID, "lanes per creature exceed one tile");
     HIP_TRY(hipSetDevice(w->cfg.device));
     int *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, ((size_t)n_tiles + 1) * sizeof(int)));
@@ -225,20 +241,21 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
 extern "C" int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                                 int32_t max_creatures, int32_t *tile_start_out, int32_t *n_tiles_out) {
     if (!parent || !jround || !tile_start_out || !n_tiles_out) return fail(REM2D_E_INVALID, "plan_tiles: NULL argument");
-    if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > V4_MAX_BODIES)
-        return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
+    const TileShape sh = tile_shape();
+    const int maxLanes = sh.passes * WAVE;
+    if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
     if (max_creatures <= 0) {
         static const int envCap = getenv("REM2D_TILE_CREATURES") ? atoi(getenv("REM2D_TILE_CREATURES")) : 0;
         max_creatures = envCap > 0 ? envCap : 32;
     }
-    const int capBodies = V4_MAX_BODIES / lanes; // creatures per tile by lanes
+    const int capBodies = maxLanes / lanes; // creatures per tile by lanes
     const int cap = max_creatures < capBodies ? max_creatures : capBodies;
     int nt = 0;
     tile_start_out[0] = 0;
-    int first = 0;        // first creature of the open tile
-    int P = 1;            // its period
-    int cnt[V4_SETS];     // its joints per phase
-    for (int s = 0; s < V4_SETS; ++s) cnt[s] = 0;
+    int first = 0;          // first creature of the open tile
+    int P = 1;              // its period
+    int cnt[V4_PHASES];     // its joints per register set (phases ph = s mod sets share set s)
+    for (int s = 0; s < V4_PHASES; ++s) cnt[s] = 0;
     auto creature_period = [&](int e) {
         int p = 1;
         if (e < n_envs)
@@ -248,39 +265,39 @@ extern "C" int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, in
             }
         return p;
     };
-    auto add_counts = [&](int e, int period, int *c) { // joints of creature e per phase under `period`
+    auto add_counts = [&](int e, int period, int *c) { // joints of creature e per register set under `period`
         if (e >= n_envs) return;
         for (int k = 0; k < lanes; ++k) {
             const size_t i = (size_t)e * lanes + k;
             if (parent[i] < 0) continue;
             const int ph = (jround[i] & 0xff) % period;
-            if (ph < V4_SETS) c[ph] += 1; // periods beyond V4_SETS are refused by the kernel (REM2D_ERR_SOLVER_OVERFLOW)
+            if (ph < V4_PHASES) c[ph % sh.sets] += 1; // periods beyond V4_PHASES are refused by the kernel (REM2D_ERR_SOLVER_OVERFLOW)
         }
     };
     for (int e = 0; e < n_padded; ++e) {
         const int pe = creature_period(e);
         bool fits = (e - first) < cap;
-        int c2[V4_SETS], P2 = P;
+        int c2[V4_PHASES], P2 = P;
+        for (int s = 0; s < V4_PHASES; ++s) c2[s] = 0;
         if (fits) {
             P2 = pe > P ? pe : P;
-            for (int s = 0; s < V4_SETS; ++s) c2[s] = 0;
             if (P2 != P) {
                 for (int x = first; x < e; ++x) add_counts(x, P2, c2);
             } else {
-                for (int s = 0; s < V4_SETS; ++s) c2[s] = cnt[s];
+                for (int s = 0; s < V4_PHASES; ++s) c2[s] = cnt[s];
             }
             add_counts(e, P2, c2);
-            for (int s = 0; s < V4_SETS; ++s) fits = fits && c2[s] <= WAVE;
+            for (int s = 0; s < V4_PHASES; ++s) fits = fits && c2[s] <= WAVE;
         }
         if (!fits && e > first) { // close the tile before e, start a new one with e
             tile_start_out[++nt] = e;
             first = e;
             P2 = pe;
-            for (int s = 0; s < V4_SETS; ++s) c2[s] = 0;
+            for (int s = 0; s < V4_PHASES; ++s) c2[s] = 0;
             add_counts(e, P2, c2);
         }
         P = P2;
-        for (int s = 0; s < V4_SETS; ++s) cnt[s] = c2[s];
+        for (int s = 0; s < V4_PHASES; ++s) cnt[s] = c2[s];
     }
     tile_start_out[++nt] = n_padded;
     *n_tiles_out = nt;
@@ -492,8 +509,16 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     memset(&B, 0, sizeof(B));
     memset(&VB, 0, sizeof(VB));
     unsigned blocks = 0, tiles = 0;
+    // tiles of the widest creatures first: their chains are the longest (period 3-4, more joint rounds), so they must
+    // not start last
+    int order[REM2D_MAX_BATCH];
+    for (int i = 0; i < n_worlds; ++i) order[i] = i;
+    for (int i = 1; i < n_worlds; ++i)
+        for (int j = i; j > 0 && ws[order[j]]->cfg.lanes > ws[order[j - 1]]->cfg.lanes; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
     for (int i = 0; i < n_worlds; ++i) {
-        rem2d_world *w = ws[i];
+        rem2d_world *w = ws[order[i]];
         B.S[i] = w->S;
         B.T[i] = w->T;
         B.lanes[i] = w->cfg.lanes;
@@ -517,11 +542,18 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     Vel4Args V;
     V.velIters = vel_iters;
     V.dt = dt;
+    static const int v4dbg = getenv("REM2D_V4_DBG") ? atoi(getenv("REM2D_V4_DBG")) : 0;
+    V.dbg = v4dbg;
     const dim3 grid(blocks), block(WAVE);
     for (int l = 0; l < n_steps; ++l) {
         hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
         const bool timed = timing_begin(w0, st);
-        hipLaunchKernelGGL(rem2d_vel4_kernel, dim3(tiles), block, 0, st, VB, V);
+        switch (tile_shape_id()) {
+        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, VB, V); break;
+        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, VB, V); break;
+        case 2: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 5>), dim3(tiles), block, 0, st, VB, V); break;
+        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, VB, V); break;
+        }
         if (timed) timing_end(w0, st);
         hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
         if (continuous) {

@@ -6,51 +6,63 @@
 // with 1/period of its lanes and a contact slot with ~5 % of them, so the population needs ~4 rounds of
 // wavefronts, each paying the whole chain.  Here a wavefront owns a TILE: a run of consecutive creatures with
 // at most 256 bodies whose joints number at most 64 in every phase of the modulo schedule (the host cuts the
-// tiles, compiler.Morphology.tiles / rem2d_world_set_tiles).  Lanes are constraints:
+// tiles, rem2d_plan_tiles / rem2d_world_set_tiles).  Lanes are constraints:
 //   * joints: lane r of register set s holds the r-th joint of phase s (joint round mod period) -- in the tick
 //     of phase s all of them fire together, so a joint slot runs with up to 64 active lanes;
-//   * contacts: every touching manifold of the tile gets a lane of its own (V4_CSETS register sets of 64);
-//     a body's manifolds are solved in list order in consecutive sub-slots (sub-slot t = the t-th manifold of
-//     every body whose contact slot is this tick);
-//   * body velocities live in an LDS mailbox ({vx, vy, w} as one 16-byte record per body); hand-offs are
-//     wave-local (lds_sync = s_waitcnt, no s_barrier).
-// The whole 65 536-creature population is ~2000 tiles, i.e. two resident wavefronts per SIMD: one round.
-// Arithmetic and ordering are those of the other forms (compiler.pipeline_schedule proves that any two
-// operations sharing a body keep Box2D's sequential order for any period >= the creature's own), so the result
-// is bit-identical to rem2d_step_kernel and to the oracle.
+//   * contacts: every touching manifold of the tile gets a lane of its own (CSETS register sets of 64).  A
+//     body's manifolds must run in list order between its last joint of one iteration and its first joint of the
+//     next (its WINDOW of ticks); manifolds of different bodies commute.  The kernel picks, per tile, the phase
+//     that lies in the window of most touching bodies and puts all their manifolds there (sub-slot t = t-th
+//     manifold), so that one iteration runs about max-manifolds-per-body contact sub-slots instead of one
+//     batch per phase;
+//   * body velocities (and 1/I) live in an LDS mailbox, one 16-byte record per body; hand-offs are wave-local
+//     (lds_sync = s_waitcnt, no s_barrier).
+// The whole 65 536-creature population is ~3000 tiles.  Arithmetic and ordering are those of the other forms
+// (compiler.pipeline_schedule proves that any two operations sharing a body keep Box2D's sequential order for
+// any period >= the creature's own), so the result is bit-identical to rem2d_step_kernel and to the oracle.
 #ifndef REM2D_VEL4_H
 #define REM2D_VEL4_H
 
-#define V4_SETS 4          // joint register sets = largest schedule period supported (reference modules: <= 4)
-#define V4_CSETS 2         // contact register sets: 128 manifolds per tile in registers, the rest through scratch
-#define V4_MAX_BODIES 256  // bodies per tile
-#define V4_PASSES (V4_MAX_BODIES / WAVE)
-#define V4_MAX_CONTACTS (V4_MAX_BODIES * KT)
+// Tile shapes (template parameters of the kernel; the host picks one per launch, rem2d.hip):
+//   SETS    joint register sets per lane.  A joint of schedule phase ph lives in set ph mod SETS; the joints of the
+//           phases that share a set take different lanes, so a tile holds at most 64 joints per set.
+//   PASSES  64-body passes of the body role: a tile holds at most 64 * PASSES bodies.
+//   CSETS   contact register sets: 64 * CSETS manifolds per tile in registers, the rest through scratch.
+//   WPS     waves per SIMD the register allocation targets.
+// More bodies per tile = fewer wavefronts and fuller joint slots; fewer registers = more resident wavefronts to hide
+// the dependent-instruction latency (~10 cycles per instruction for a lone wavefront, measured with s_memtime).
+#define V4_PHASES 4        // largest schedule period supported (reference modules: <= 4)
+#define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
+#define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
-struct Vel4Args { int velIters; float dt; };
+struct Vel4Args { int velIters; float dt; int dbg; /* REM2D_V4_DBG: 1 skip contact sub-slots, 2 skip joint slots (timing probes only) */ };
 
-struct __attribute__((aligned(16))) V4Vel { float x, y, w, pad; };
-struct Vel4Shared {
-    V4Vel vel[V4_MAX_BODIES];
-    unsigned short jmap[V4_SETS][WAVE];     // (set, lane) -> tile-local body id of the joint's child, 0xffff = none
-    unsigned short cmap[V4_MAX_CONTACTS];   // contact rank -> tile-local body id | manifold index << 8
+struct __attribute__((aligned(16))) V4Vel { float x, y, w, invI; };
+template <int SETS, int PASSES> struct Vel4Shared {
+    V4Vel vel[PASSES * WAVE];
+    unsigned short jmap[SETS][WAVE];        // (set, lane) -> tile-local body id of the joint's child, 0xffff = none
+    unsigned int cmap[PASSES * WAVE * KT];  // contact rank -> V4_C* key (body, sub-slot, manifold index, tick offset)
+    int firstR[PASSES * WAVE], lastR[PASSES * WAVE]; // first / last joint round of every body (own joint and children's)
 };
 
-// one joint: what the 180 iterations read (constants) and write (accumulated impulses)
+// one joint: what the 180 iterations read (constants) and write (accumulated impulses).  The inverse inertias come
+// with the velocity records; the limit-only terms of the 3x3 mass matrix (ezx, ezy, ezz and its cofactors) are
+// recomputed where the limit is active -- the same expressions on the same operands, hence the same bits.
 struct JointT {
     V2 rA, rB;
-    float mA, iA, mB, iB;
-    float exx, eyx, ezx, eyy, ezy, ezz, motorMass, det33, det22, cyzx, cyzy, cyzz;
+    float mA, mB;
+    float exx, eyx, eyy, motorMass, det33, det22;
     float impX, impY, impZ, motorImp, motorSpeed, maxMotorImpulse;
-    int key; // jA | jB << 8 | jround << 16 | limitState << 24 | valid << 31
+    int key; // jA | jB << 8 | jround << 16 | limitState << 24 | phase << 26 | valid << 31
 };
 #define V4_JA(k) ((k) & 0xff)
 #define V4_JB(k) (((k) >> 8) & 0xff)
 #define V4_JROUND(k) (((k) >> 16) & 0xff)
 #define V4_LIMIT(k) (((k) >> 24) & 0x3)
+#define V4_JPHASE(k) (((k) >> 26) & 0x7)
 #define V4_VALID(k) ((k) < 0)
 
-DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, JointT &J) {
+DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, int P, JointT &J) {
     const unsigned Lp = S.Lp;
     const unsigned gl = tb0 + (unsigned)child;
     const int jA = (child & ~(K - 1)) + LI(L_PARENT);
@@ -58,31 +70,33 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
     const unsigned jb = (unsigned)SCR_JREC_BASE * Lp + gl;
     J.rA = mk(SW(jb, 0), SW(jb, 1));
     J.rB = mk(SW(jb, 2), SW(jb, 3));
-    J.mB = LF(L_INVM); J.iB = LF(L_INVI);
+    J.mB = LF(L_INVM);
+    const float iB = LF(L_INVI);
     J.impX = LF(L_JIMPX); J.impY = LF(L_JIMPY); J.impZ = LF(L_JIMPZ); J.motorImp = LF(L_JMOTORIMP);
     J.motorSpeed = LF(L_JMOTORSPEED);
     const int limitState = LI(L_JLIMIT);
     J.maxMotorImpulse = h * LF(L_JTORQUE);
+    float iA;
     {
         const unsigned gl = tb0 + (unsigned)jA;
-        J.mA = LF(L_INVM); J.iA = LF(L_INVI);
+        J.mA = LF(L_INVM); iA = LF(L_INVI);
     }
-    J.key = jA | (child << 8) | (jround << 16) | (limitState << 24) | (int)0x80000000;
-    const float mA = J.mA, iA = J.iA, mB = J.mB, iB = J.iB;
+    J.key = jA | (child << 8) | (jround << 16) | (limitState << 24) | ((jround % P) << 26) | (int)0x80000000;
+    const float mA = J.mA, mB = J.mB;
     const V2 rA = J.rA, rB = J.rB;
     // effective-mass terms of b2RevoluteJoint::InitVelocityConstraints (same expressions as rem2d_step_kernel)
     J.exx = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
     J.eyx = -rA.y * rA.x * iA - rB.y * rB.x * iB;
-    J.ezx = -rA.y * iA - rB.y * iB;
+    const float ezx = -rA.y * iA - rB.y * iB;
     J.eyy = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
-    J.ezy = rA.x * iA + rB.x * iB;
-    J.ezz = iA + iB;
+    const float ezy = rA.x * iA + rB.x * iB;
+    const float ezz = iA + iB;
     J.motorMass = iA + iB;
     if (J.motorMass > 0.0f) J.motorMass = 1.0f / J.motorMass;
-    J.cyzx = J.eyy * J.ezz - J.ezy * J.ezy;
-    J.cyzy = J.ezy * J.ezx - J.eyx * J.ezz;
-    J.cyzz = J.eyx * J.ezy - J.eyy * J.ezx;
-    J.det33 = J.exx * J.cyzx + J.eyx * J.cyzy + J.ezx * J.cyzz;
+    const float cyzx = J.eyy * ezz - ezy * ezy;
+    const float cyzy = ezy * ezx - J.eyx * ezz;
+    const float cyzz = J.eyx * ezy - J.eyy * ezx;
+    J.det33 = J.exx * cyzx + J.eyx * cyzy + ezx * cyzz;
     if (J.det33 != 0.0f) J.det33 = 1.0f / J.det33;
     J.det22 = J.exx * J.eyy - J.eyx * J.eyx;
     if (J.det22 != 0.0f) J.det22 = 1.0f / J.det22;
@@ -90,29 +104,37 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
 
 // b2RevoluteJoint::SolveVelocityConstraints (motor, then limit 3x3 / point 2x2) on the mailbox records of the
 // joint's two bodies; same expression sequence as the joint slot of rem2d_step_kernel
-DEV void v4_joint_slot(JointT &j, Vel4Shared &sh) {
+template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
     const int a = V4_JA(j.key), b = V4_JB(j.key), limitState = V4_LIMIT(j.key);
-    const V4Vel ra = sh.vel[a], rb = sh.vel[b];
+    V4Vel ra = sh.vel[a], rb = sh.vel[b];
     V2 vA = mk(ra.x, ra.y), vB = mk(rb.x, rb.y);
     float wA = ra.w, wB = rb.w;
+    const float iA = ra.invI, iB = rb.invI;
     if (limitState != LIM_EQUAL) {
         float Cdot = wB - wA - j.motorSpeed;
         float impulse = -j.motorMass * Cdot;
         float oldImpulse = j.motorImp;
         j.motorImp = fclamp(oldImpulse + impulse, -j.maxMotorImpulse, j.maxMotorImpulse);
         impulse = j.motorImp - oldImpulse;
-        wA -= j.iA * impulse;
-        wB += j.iB * impulse;
+        wA -= iA * impulse;
+        wB += iB * impulse;
     }
     if (limitState != LIM_INACTIVE) {
+        // ex = (exx, eyx, ezx), ey = (eyx, eyy, ezy), ez = (ezx, ezy, ezz) of m_mass; cyz = cross(ey, ez)
+        const float ezx = -j.rA.y * iA - j.rB.y * iB;
+        const float ezy = j.rA.x * iA + j.rB.x * iB;
+        const float ezz = iA + iB;
+        const float cyzx = j.eyy * ezz - ezy * ezy;
+        const float cyzy = ezy * ezx - j.eyx * ezz;
+        const float cyzz = j.eyx * ezy - j.eyy * ezx;
         V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
         float Cdot2 = wB - wA;
         float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
-        float sx = j.det33 * (bx * j.cyzx + by * j.cyzy + bz * j.cyzz);
-        float cbx = by * j.ezz - bz * j.ezy, cby = bz * j.ezx - bx * j.ezz, cbz = bx * j.ezy - by * j.ezx;
-        float sy = j.det33 * (j.exx * cbx + j.eyx * cby + j.ezx * cbz);
-        float ebx = j.eyy * bz - j.ezy * by, eby = j.ezy * bx - j.eyx * bz, ebz = j.eyx * by - j.eyy * bx;
-        float sz = j.det33 * (j.exx * ebx + j.eyx * eby + j.ezx * ebz);
+        float sx = j.det33 * (bx * cyzx + by * cyzy + bz * cyzz);
+        float cbx = by * ezz - bz * ezy, cby = bz * ezx - bx * ezz, cbz = bx * ezy - by * ezx;
+        float sy = j.det33 * (j.exx * cbx + j.eyx * cby + ezx * cbz);
+        float ebx = j.eyy * bz - ezy * by, eby = ezy * bx - j.eyx * bz, ebz = j.eyx * by - j.eyy * bx;
+        float sz = j.det33 * (j.exx * ebx + j.eyx * eby + ezx * ebz);
         float ix = -sx, iy = -sy, iz = -sz;
         if (limitState == LIM_EQUAL) {
             j.impX += ix; j.impY += iy; j.impZ += iz;
@@ -120,7 +142,7 @@ DEV void v4_joint_slot(JointT &j, Vel4Shared &sh) {
             float newImpulse = j.impZ + iz;
             bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
             if (reduce) {
-                V2 rhs = vadd(vneg(Cdot1), vscale(j.impZ, mk(j.ezx, j.ezy)));
+                V2 rhs = vadd(vneg(Cdot1), vscale(j.impZ, mk(ezx, ezy)));
                 float rx = j.det22 * (j.eyy * rhs.x - j.eyx * rhs.y);
                 float ry = j.det22 * (j.exx * rhs.y - j.eyx * rhs.x);
                 ix = rx; iy = ry; iz = -j.impZ;
@@ -131,38 +153,75 @@ DEV void v4_joint_slot(JointT &j, Vel4Shared &sh) {
         }
         V2 P = mk(ix, iy);
         vA = vsub(vA, vscale(j.mA, P));
-        wA -= j.iA * (vcross(j.rA, P) + iz);
+        wA -= iA * (vcross(j.rA, P) + iz);
         vB = vadd(vB, vscale(j.mB, P));
-        wB += j.iB * (vcross(j.rB, P) + iz);
+        wB += iB * (vcross(j.rB, P) + iz);
     } else {
         V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
         V2 bb = vneg(Cdot);
         V2 impulse = mk(j.det22 * (j.eyy * bb.x - j.eyx * bb.y), j.det22 * (j.exx * bb.y - j.eyx * bb.x));
         j.impX += impulse.x; j.impY += impulse.y;
         vA = vsub(vA, vscale(j.mA, impulse));
-        wA -= j.iA * vcross(j.rA, impulse);
+        wA -= iA * vcross(j.rA, impulse);
         vB = vadd(vB, vscale(j.mB, impulse));
-        wB += j.iB * vcross(j.rB, impulse);
+        wB += iB * vcross(j.rB, impulse);
     }
-    V4Vel oa, ob;
-    oa.x = vA.x; oa.y = vA.y; oa.w = wA; oa.pad = 0.0f;
-    ob.x = vB.x; ob.y = vB.y; ob.w = wB; ob.pad = 0.0f;
-    sh.vel[a] = oa;
-    sh.vel[b] = ob;
+    ra.x = vA.x; ra.y = vA.y; ra.w = wA;
+    rb.x = vB.x; rb.y = vB.y; rb.w = wB;
+    sh.vel[a] = ra;
+    sh.vel[b] = rb;
 }
 
-// one contact lane: the manifold's constraint, its body's inverse mass / inertia and its place in the schedule
+// one contact lane: the manifold's constraint, its body's inverse mass and its place in the schedule
 struct ContactT {
     ContactC c;
-    float mB, iB;
-    int key; // body | manifold index << 8 | offC << 16 | (offC mod P) << 24 | valid << 31
+    float mB;
+    int key; // body | sub-slot << 8 | manifold index << 11 | first tick << 16 | (first tick mod P) << 24 | valid << 31
 };
 #define V4_CBODY(k) ((k) & 0xff)
-#define V4_CT(k) (((k) >> 8) & 0xff)
+#define V4_CSUB(k) (((k) >> 8) & 0x7)
+#define V4_CT(k) (((k) >> 11) & 0x7)
 #define V4_COFF(k) (((k) >> 16) & 0xff)
 #define V4_CPHASE(k) (((k) >> 24) & 0x7)
 
-DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsigned tile, int K, Vel4Shared &sh) {
+// the contact sub-slots of the tick `tick` (phase ph): every manifold scheduled here, in the order of its body's list
+template <int CSETS, typename SH>
+DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsigned tb0, int lane, int NC, bool spill,
+                             int nsub, int ph, int tick, int span, float mu) {
+    const unsigned Lp = S.Lp;
+    for (int t = 0; t < nsub; ++t) {
+#pragma unroll
+        for (int cs = 0; cs < CSETS; ++cs) {
+            // off = ph (mod P) and off <= tick < off + iters P: the manifold runs in this tick, in sub-slot `sub`
+            if (V4_VALID(C[cs].key) && V4_CSUB(C[cs].key) == t && V4_CPHASE(C[cs].key) == ph &&
+                (unsigned)(tick - V4_COFF(C[cs].key)) < (unsigned)span) {
+                const int b = V4_CBODY(C[cs].key);
+                V4Vel v = sh.vel[b];
+                contact_solve(C[cs].c, C[cs].mB, v.invI, mu, v.x, v.y, v.w);
+                sh.vel[b] = v;
+            }
+        }
+        if (spill) {
+            for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+                const int e = (int)sh.cmap[ci];
+                const int b = V4_CBODY(e);
+                if (V4_CSUB(e) != t || V4_CPHASE(e) != ph || !((unsigned)(tick - V4_COFF(e)) < (unsigned)span)) continue;
+                const unsigned gl = tb0 + (unsigned)b;
+                const unsigned cb = (unsigned)(SCR_CC_BASE + V4_CT(e) * CC_WORDS) * Lp + gl;
+                ContactC c;
+                cc_load(S, cb, c);
+                V4Vel v = sh.vel[b];
+                contact_solve(c, LF(L_INVM), v.invI, mu, v.x, v.y, v.w);
+                sh.vel[b] = v;
+                SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+            }
+        }
+        lds_sync();
+    }
+}
+
+template <int SETS, int PASSES, int CSETS>
+DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsigned tile, int K, Vel4Shared<SETS, PASSES> &sh) {
     const int lane = threadIdx.x;
     const unsigned Lp = S.Lp;
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
@@ -181,121 +240,169 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     }
 
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) sh.jmap[s][lane] = 0xffff;
+    for (int s = 0; s < SETS; ++s) sh.jmap[s][lane] = 0xffff;
     // ---------------- body role (<= 4 passes of 64 bodies): publish velocities, deal joints and manifolds to lanes ----------------
-    int sched[V4_PASSES], misc[V4_PASSES], parent[V4_PASSES];
+    int sched[PASSES], misc[PASSES], parent[PASSES];
     int P = 1;
 #pragma unroll
-    for (int p = 0; p < V4_PASSES; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
         const unsigned gl = tb0 + (unsigned)bl;
         sched[p] = 0; misc[p] = 0; parent[p] = -1;
+        sh.firstR[bl] = 0x7fffffff;
+        sh.lastR[bl] = -1;
         if (bl < NB) {
             misc[p] = __float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 0));
             sched[p] = LI(L_JROUND);
             parent[p] = LI(L_PARENT);
             V4Vel v;
-            v.x = LF(L_VX); v.y = LF(L_VY); v.w = LF(L_W); v.pad = 0.0f;
+            v.x = LF(L_VX); v.y = LF(L_VY); v.w = LF(L_W); v.invI = LF(L_INVI);
             sh.vel[bl] = v;
         }
         P = max(P, (sched[p] >> 16) & 0xff); // every creature of the tile, awake or not: the host cut the tile with this period
     }
     P = wave_max(P);
-    int NC = 0, lastTick = -1, maxRound = -1, err = 0;
-    int jcount[V4_SETS];
+    lds_sync();
+    // ---- every body's contact window.  Body b's manifolds of iteration i may run anywhere after its last joint of
+    // that iteration (round last[b]) and before its first joint of the next one (round first[b] + P): ticks
+    // last[b] .. first[b] + P - 1 (+ i P).  The host's contact slot offC[b] is one tick of that window.
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) jcount[s] = 0;
-    int subMax[V4_SETS]; // contact sub-slots per phase = most manifolds on one body whose contact slot has that phase
+    for (int p = 0; p < PASSES; ++p) {
+        const int bl = p * WAVE + lane;
+        if ((misc[p] & 0x100) != 0 && parent[p] >= 0) {
+            const int jr = sched[p] & 0xff, pl = (bl & ~(K - 1)) + parent[p];
+            atomicMin(&sh.firstR[bl], jr); atomicMax(&sh.lastR[bl], jr);
+            atomicMin(&sh.firstR[pl], jr); atomicMax(&sh.lastR[pl], jr);
+        }
+    }
+    lds_sync();
+    // ---- the tile's contact phase: the phase inside the window of the most touching bodies (ties: the later phase,
+    // the host's own preference).  Bodies whose window holds it run all their manifolds there, one per sub-slot; the
+    // others run theirs in the first tick of their window.
+    int wlo[PASSES], wlen[PASSES], cover[V4_PHASES];
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) subMax[s] = 0;
+    for (int s = 0; s < V4_PHASES; ++s) cover[s] = 0;
 #pragma unroll
-    for (int p = 0; p < V4_PASSES; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
+        const int bl = p * WAVE + lane;
+        const bool solve = (misc[p] & 0x100) != 0;
+        const int nT = solve ? (misc[p] & 0xff) : 0;
+        const int lastB = sh.lastR[bl];
+        wlo[p] = lastB >= 0 ? lastB : 0;                          // first tick of the window (iteration 0)
+        wlen[p] = lastB >= 0 ? sh.firstR[bl] + P - lastB : P;     // its length in ticks, 1 .. P
+        const int wl = wlo[p] % P;
+#pragma unroll
+        for (int s = 0; s < V4_PHASES; ++s) {
+            int d = s - wl;
+            d = d < 0 ? d + P : d;
+            cover[s] += __popcll(__ballot(nT > 0 && s < P && d < wlen[p]));
+        }
+    }
+    int cstar = 0;
+#pragma unroll
+    for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
+
+    int NC = 0, lastTick = -1, maxRound = -1, err = 0, maxT = 0;
+    int jcount[SETS]; // lanes handed out in every register set (the phases ph = s mod SETS share set s)
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) jcount[s] = 0;
+    int subMax[V4_PHASES]; // contact sub-slots per phase = most manifolds any body runs in a tick of that phase
+#pragma unroll
+    for (int s = 0; s < V4_PHASES; ++s) subMax[s] = 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
         const bool solve = (misc[p] & 0x100) != 0;
         const bool hasJ = solve && parent[p] >= 0;
         const int nT = solve ? (misc[p] & 0xff) : 0;
-        const int jr = sched[p] & 0xff, oc = (sched[p] >> 8) & 0xff;
-        const int phase = jr % P, cphase = oc % P;
+        const int jr = sched[p] & 0xff;
+        const int phase = jr % P;
 #pragma unroll
-        for (int s = 0; s < V4_SETS; ++s) {
-            const unsigned long long m = __ballot(hasJ && phase == s);
-            if (hasJ && phase == s) {
+        for (int s = 0; s < SETS; ++s) {
+            const unsigned long long m = __ballot(hasJ && phase % SETS == s);
+            if (hasJ && phase % SETS == s) {
                 const int rank = jcount[s] + __popcll(m & below);
                 if (rank < WAVE) sh.jmap[s][rank] = (unsigned short)bl;
-                else err = REM2D_ERR_SOLVER_OVERFLOW; // the tile breaks the host's rule (<= 64 joints per phase)
+                else err = REM2D_ERR_SOLVER_OVERFLOW; // the tile breaks the host's rule (<= 64 joints per register set)
             }
             jcount[s] += __popcll(m);
-            if (nT > 0 && cphase == s) subMax[s] = max(subMax[s], nT);
         }
-        if (hasJ && phase >= V4_SETS) err = REM2D_ERR_SOLVER_OVERFLOW;
-        if (nT > 0 && cphase >= V4_SETS) err = REM2D_ERR_SOLVER_OVERFLOW;
+        if (hasJ && phase >= V4_PHASES) err = REM2D_ERR_SOLVER_OVERFLOW;
+        int dstar = cstar - wlo[p] % P;
+        dstar = dstar < 0 ? dstar + P : dstar;
+        const int off = wlo[p] + (dstar < wlen[p] ? dstar : 0); // the tile's contact phase if the window holds it
+        const int cph = off % P;
+        if (nT > 0) {
 #pragma unroll
-        for (int t = 0; t < KT; ++t) { // manifold t of every body: ranks in (pass, t, lane) order
+            for (int s = 0; s < V4_PHASES; ++s)
+                if (cph == s) subMax[s] = max(subMax[s], nT);
+            if (cph >= V4_PHASES) err = REM2D_ERR_SOLVER_OVERFLOW;
+            if (iters > 0) lastTick = max(lastTick, off + (iters - 1) * P);
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) { // manifold t of every body: ranks in (pass, t, lane) order, sub-slot t
             const unsigned long long cm = __ballot(nT > t);
-            if (nT > t) sh.cmap[NC + __popcll(cm & below)] = (unsigned short)(bl | (t << 8));
+            if (nT > t) sh.cmap[NC + __popcll(cm & below)] = (unsigned)(bl | (t << 8) | (t << 11) | (off << 16) | (cph << 24));
             NC += __popcll(cm);
         }
-        if (iters > 0) {
-            if (hasJ) lastTick = max(lastTick, jr + (iters - 1) * P);
-            if (nT > 0) lastTick = max(lastTick, oc + (iters - 1) * P);
-        }
+        maxT = max(maxT, nT);
+        if (iters > 0 && hasJ) lastTick = max(lastTick, jr + (iters - 1) * P);
         if (hasJ) maxRound = max(maxRound, jr);
     }
     const int nTicks = wave_max(lastTick) + 1;
     const int nRounds = wave_max(maxRound) + 1;
-    int maxSub = 0;
+    maxT = wave_max(maxT);
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) { subMax[s] = wave_max(subMax[s]); maxSub = max(maxSub, subMax[s]); }
+    for (int s = 0; s < V4_PHASES; ++s) subMax[s] = (A.dbg & 1) ? 0 : wave_max(subMax[s]);
     lds_sync();
 
     // ---------------- joint role: one joint per phase and lane ----------------
-    JointT J[V4_SETS];
+    JointT J[SETS];
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) {
+    for (int s = 0; s < SETS; ++s) {
         J[s].key = 0;
         const int child = sh.jmap[s][lane];
-        if (s < P && child != 0xffff) v4_joint_load(S, tb0, K, child, h, J[s]);
+        if (child != 0xffff) v4_joint_load(S, tb0, K, child, h, P, J[s]);
     }
-    // ---------------- contact role: manifold `lane + 64 cs` of the tile; beyond V4_CSETS * 64 through scratch ----------------
-    ContactT C[V4_CSETS];
+    // ---------------- contact role: manifold `lane + 64 cs` of the tile; beyond CSETS * 64 through scratch ----------------
+    ContactT C[CSETS];
 #pragma unroll
-    for (int cs = 0; cs < V4_CSETS; ++cs) {
+    for (int cs = 0; cs < CSETS; ++cs) {
         C[cs].key = 0;
         C[cs].c.count = 0;
-        C[cs].mB = C[cs].iB = 0.0f;
+        C[cs].mB = 0.0f;
         const int ci = cs * WAVE + lane;
         if (ci < NC) {
-            const int e = sh.cmap[ci];
-            const int b = e & 0xff, t = e >> 8;
+            const int e = (int)sh.cmap[ci];
+            const int b = V4_CBODY(e), t = V4_CT(e);
             const unsigned gl = tb0 + (unsigned)b;
-            const int oc = (LI(L_JROUND) >> 8) & 0xff;
-            C[cs].key = b | (t << 8) | (oc << 16) | ((oc % P) << 24) | (int)0x80000000;
-            C[cs].mB = LF(L_INVM); C[cs].iB = LF(L_INVI);
+            C[cs].key = e | (int)0x80000000;
+            C[cs].mB = LF(L_INVM);
             cc_load(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, C[cs].c);
         }
     }
-    const bool spill = NC > V4_CSETS * WAVE; // wave-uniform
+    const bool spill = NC > CSETS * WAVE; // wave-uniform
     // ---------------- warm start: contacts (per body in list order), then joints in island rounds ----------------
-    for (int t = 0; t < maxSub; ++t) {
+    for (int t = 0; t < maxT; ++t) {
 #pragma unroll
-        for (int cs = 0; cs < V4_CSETS; ++cs) {
+        for (int cs = 0; cs < CSETS; ++cs) {
             if (V4_VALID(C[cs].key) && V4_CT(C[cs].key) == t) {
                 const int b = V4_CBODY(C[cs].key);
                 V4Vel v = sh.vel[b];
-                contact_warm_start(C[cs].c, C[cs].mB, C[cs].iB, v.x, v.y, v.w);
+                contact_warm_start(C[cs].c, C[cs].mB, v.invI, v.x, v.y, v.w);
                 sh.vel[b] = v;
             }
         }
         if (spill) {
-            for (int ci = V4_CSETS * WAVE + lane; ci < NC; ci += WAVE) {
-                const int e = sh.cmap[ci];
-                const int b = e & 0xff;
-                if ((e >> 8) != t) continue;
+            for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+                const int e = (int)sh.cmap[ci];
+                const int b = V4_CBODY(e);
+                if (V4_CT(e) != t) continue;
                 const unsigned gl = tb0 + (unsigned)b;
                 ContactC c;
                 cc_load(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
                 V4Vel v = sh.vel[b];
-                contact_warm_start(c, LF(L_INVM), LF(L_INVI), v.x, v.y, v.w);
+                contact_warm_start(c, LF(L_INVM), v.invI, v.x, v.y, v.w);
                 sh.vel[b] = v;
             }
         }
@@ -303,7 +410,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     }
     for (int r = 0; r < nRounds; ++r) {
 #pragma unroll
-        for (int s = 0; s < V4_SETS; ++s) {
+        for (int s = 0; s < SETS; ++s) {
             if (V4_VALID(J[s].key) && V4_JROUND(J[s].key) == r) {
                 const int a = V4_JA(J[s].key), b = V4_JB(J[s].key);
                 V4Vel ra = sh.vel[a], rb = sh.vel[b];
@@ -311,9 +418,9 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                 float wA = ra.w, wB = rb.w;
                 V2 Pw = mk(J[s].impX, J[s].impY);
                 vA = vsub(vA, vscale(J[s].mA, Pw));
-                wA -= J[s].iA * (vcross(J[s].rA, Pw) + J[s].motorImp + J[s].impZ);
+                wA -= ra.invI * (vcross(J[s].rA, Pw) + J[s].motorImp + J[s].impZ);
                 vB = vadd(vB, vscale(J[s].mB, Pw));
-                wB += J[s].iB * (vcross(J[s].rB, Pw) + J[s].motorImp + J[s].impZ);
+                wB += rb.invI * (vcross(J[s].rB, Pw) + J[s].motorImp + J[s].impZ);
                 ra.x = vA.x; ra.y = vA.y; ra.w = wA;
                 rb.x = vB.x; rb.y = vB.y; rb.w = wB;
                 sh.vel[a] = ra;
@@ -322,60 +429,43 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
         lds_sync();
     }
-    // ---------------- velocity iterations ----------------
+    // ---------------- velocity iterations: ticks in groups of one period, phase = position in the group ----------------
     {
         const int span = iters * P; // joint k fires at ticks jround + i P, i < iters, i.e. while tick - jround < span
-        int ph = 0;
-        for (int tick = 0; tick < nTicks; ++tick) {
-            // joint slot: the register set of this tick's phase (wave-uniform switch)
+        const bool joints = !(A.dbg & 2);
+        const bool stamp = (A.dbg & 8) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py)
+        unsigned long long tJ = 0, tC = 0, t0 = 0, t1 = 0, nSub = 0;
+        const unsigned long long tStart = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        for (int base = 0; base < nTicks; base += P) {
 #pragma unroll
-            for (int s = 0; s < V4_SETS; ++s) {
-                if (s == ph) {
-                    if (V4_VALID(J[s].key) && (unsigned)(tick - V4_JROUND(J[s].key)) < (unsigned)span) v4_joint_slot(J[s], sh);
+            for (int s = 0; s < V4_PHASES; ++s) {
+                if (s < P) {
+                    const int tick = base + s;
+                    if (stamp) t0 = __builtin_amdgcn_s_memtime();
+                    // the joints of phase s: register set s mod SETS, the lanes whose joint has that phase
+                    JointT &Js = J[s % SETS];
+                    if (joints && V4_VALID(Js.key) && (SETS == V4_PHASES || V4_JPHASE(Js.key) == s) &&
+                        (unsigned)(tick - V4_JROUND(Js.key)) < (unsigned)span) v4_joint_slot(Js, sh);
+                    lds_sync();
+                    if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tJ += t1 - t0; }
+                    v4_contact_subslots(S, C, sh, tb0, lane, NC, spill, subMax[s], s, tick, span, mu);
+                    if (stamp) { tC += __builtin_amdgcn_s_memtime() - t1; nSub += subMax[s]; }
                 }
             }
-            lds_sync();
-            // contact sub-slots of the bodies whose contact slot is this tick
-            int nsub = 0;
-#pragma unroll
-            for (int s = 0; s < V4_SETS; ++s) nsub = (s == ph) ? subMax[s] : nsub;
-            for (int t = 0; t < nsub; ++t) {
-#pragma unroll
-                for (int cs = 0; cs < V4_CSETS; ++cs) {
-                    // offC = ph (mod P) and offC <= tick < offC + iters P: this tick is the body's contact slot
-                    if (V4_VALID(C[cs].key) && V4_CT(C[cs].key) == t && V4_CPHASE(C[cs].key) == ph &&
-                        (unsigned)(tick - V4_COFF(C[cs].key)) < (unsigned)span) {
-                        const int b = V4_CBODY(C[cs].key);
-                        V4Vel v = sh.vel[b];
-                        contact_solve(C[cs].c, C[cs].mB, C[cs].iB, mu, v.x, v.y, v.w);
-                        sh.vel[b] = v;
-                    }
-                }
-                if (spill) {
-                    for (int ci = V4_CSETS * WAVE + lane; ci < NC; ci += WAVE) {
-                        const int e = sh.cmap[ci];
-                        const int b = e & 0xff;
-                        if ((e >> 8) != t) continue;
-                        const unsigned gl = tb0 + (unsigned)b;
-                        const int d = tick - ((LI(L_JROUND) >> 8) & 0xff);
-                        if (!((unsigned)d < (unsigned)span && d % P == 0)) continue;
-                        const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
-                        ContactC c;
-                        cc_load(S, cb, c);
-                        V4Vel v = sh.vel[b];
-                        contact_solve(c, LF(L_INVM), LF(L_INVI), mu, v.x, v.y, v.w);
-                        sh.vel[b] = v;
-                        SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
-                    }
-                }
-                lds_sync();
-            }
-            ph = ph + 1 == P ? 0 : ph + 1;
+        }
+        if (stamp && lane == 0 && c1 - c0 >= 5) { // debug words in the (otherwise unused while stepping) TOI event counters
+            const unsigned long long tAll = __builtin_amdgcn_s_memtime() - tStart;
+            unsigned env = (unsigned)c0;
+            EI(E_TOIEVENTS) = (int)(tJ >> 4);
+            env = (unsigned)c0 + 1; EI(E_TOIEVENTS) = (int)(tC >> 4);
+            env = (unsigned)c0 + 2; EI(E_TOIEVENTS) = (int)(tAll >> 4);
+            env = (unsigned)c0 + 3; EI(E_TOIEVENTS) = (int)nSub;
+            env = (unsigned)c0 + 4; EI(E_TOIEVENTS) = nTicks;
         }
     }
     // ---------------- StoreImpulses, joint impulses, body velocities ----------------
 #pragma unroll
-    for (int cs = 0; cs < V4_CSETS; ++cs) {
+    for (int cs = 0; cs < CSETS; ++cs) {
         if (V4_VALID(C[cs].key)) {
             const int b = V4_CBODY(C[cs].key), t = V4_CT(C[cs].key);
             const unsigned gl = tb0 + (unsigned)b;
@@ -390,9 +480,9 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
     if (spill) {
-        for (int ci = V4_CSETS * WAVE + lane; ci < NC; ci += WAVE) {
-            const int e = sh.cmap[ci];
-            const int b = e & 0xff, t = e >> 8;
+        for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+            const int e = (int)sh.cmap[ci];
+            const int b = V4_CBODY(e), t = V4_CT(e);
             const unsigned gl = tb0 + (unsigned)b;
             const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
             const unsigned sp = (unsigned)__float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 1));
@@ -406,14 +496,14 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
 #pragma unroll
-    for (int s = 0; s < V4_SETS; ++s) {
+    for (int s = 0; s < SETS; ++s) {
         if (V4_VALID(J[s].key)) {
             const unsigned gl = tb0 + (unsigned)V4_JB(J[s].key);
             LF(L_JIMPX) = J[s].impX; LF(L_JIMPY) = J[s].impY; LF(L_JIMPZ) = J[s].impZ; LF(L_JMOTORIMP) = J[s].motorImp;
         }
     }
 #pragma unroll
-    for (int p = 0; p < V4_PASSES; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
         if (misc[p] & 0x100) {
             const unsigned gl = tb0 + (unsigned)bl;
@@ -436,13 +526,14 @@ struct Vel4Batch {
     int lanes[REM2D_MAX_BATCH];
     int n;
 };
-__global__ __launch_bounds__(WAVE, 2) void rem2d_vel4_kernel(Vel4Batch B, Vel4Args A) {
-    __shared__ Vel4Shared sh;
+template <int SETS, int PASSES, int CSETS, int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void rem2d_vel4_kernel(Vel4Batch B, Vel4Args A) {
+    __shared__ Vel4Shared<SETS, PASSES> sh;
     unsigned tile = blockIdx.x;
     int b = 0;
     while (b + 1 < B.n && tile >= B.tileEnd[b]) ++b;
     if (b > 0) tile -= B.tileEnd[b - 1];
-    vel4_body(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
+    vel4_body<SETS, PASSES, CSETS>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
 }
 
 #endif

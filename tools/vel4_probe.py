@@ -8,6 +8,51 @@ import bench
 from gym_rem2d_amd import make_terrain
 from gym_rem2d_amd.world import BatchedWorld
 
+def subslot_stats(w, m, n_sample=200):
+    """Host replica of rem2d_vel4_kernel's manifold schedule: sub-slot executions per iteration and tile."""
+    K = m.lanes
+    tiles = w.tiles
+    nt_all = ((w.view("cinfo").cpu().numpy() & 0xff) > 0).sum(0).reshape(-1)[: m.n_envs * K].reshape(m.n_envs, K)
+    jr_all = m.arrays["jround"].reshape(m.n_envs, K)
+    par_all = m.arrays["parent"].reshape(m.n_envs, K)
+    awake = w.view("awake").cpu().numpy().reshape(-1)[: m.n_envs * K].reshape(m.n_envs, K)
+    rows = []
+    for ti in np.linspace(0, len(tiles) - 2, min(n_sample, len(tiles) - 1)).astype(int):
+        a, b = tiles[ti], min(tiles[ti + 1], m.n_envs)
+        if b <= a:
+            continue
+        jr, par, nt = jr_all[a:b], par_all[a:b], nt_all[a:b]
+        P = max(1, int(((jr >> 16) & 0xff).max()))
+        sub_max = np.zeros(P, dtype=int)
+        one_slot = np.zeros(P, dtype=int)
+        for c in range(b - a):
+            first = np.full(K, 10 ** 6); last = np.full(K, -1)
+            for k in range(K):
+                if par[c, k] >= 0:
+                    r = jr[c, k] & 0xff
+                    for x in (k, par[c, k]):
+                        first[x] = min(first[x], r); last[x] = max(last[x], r)
+            for k in range(K):
+                n = nt[c, k]
+                if n == 0:
+                    continue
+                wlo = last[k] if last[k] >= 0 else 0
+                wlen = first[k] + P - last[k] if last[k] >= 0 else P
+                prev, sub = -1, 0
+                for t in range(n):
+                    j = (t * wlen) // n
+                    sub = sub + 1 if j == prev else 0
+                    prev = j
+                    ph = (wlo + j) % P
+                    sub_max[ph] = max(sub_max[ph], sub + 1)
+                oc = (jr[c, k] >> 8) & 0xff
+                one_slot[oc % P] = max(one_slot[oc % P], n)
+        rows.append((P, sub_max.sum(), one_slot.sum(), nt.max(), (nt > 0).sum(), nt.sum()))
+    r = np.array(rows)
+    print("   sampled %d tiles: period %.2f, sub-slots/iteration spread %.2f (single slot at offC: %.2f), max manifolds on a body %.2f, "
+          "touching bodies %.1f, manifolds %.1f" % (len(r), r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean(), r[:, 3].mean(), r[:, 4].mean(), r[:, 5].mean()))
+
+
 workload = sys.argv[1] if len(sys.argv) > 1 else "lsystem"
 morphs, desc = bench.build_population(workload, 65536, 0)
 terrain = make_terrain(4, flat=True)
@@ -29,4 +74,13 @@ for m in morphs:
     per_tile = np.add.reduceat(ct.sum(0).reshape(-1)[: m.n_envs * m.lanes].reshape(m.n_envs, m.lanes).sum(1), w.tiles[:-1][w.tiles[:-1] < m.n_envs])
     print("lanes %2d envs %6d tiles %5d (creatures/tile %.1f) vel4 %.3f ms  step wall %.3f ms  manifolds/tile mean %.1f max %d  >128: %d" %
           (m.lanes, m.n_envs, len(sizes), sizes.mean(), ms / max(1, n), wall, per_tile.mean(), per_tile.max(), (per_tile > 128).sum()))
+    if os.environ.get("REM2D_V4_DBG", "0") == "8":
+        ev = w.view("toievents").cpu().numpy()
+        t = w.tiles[:-1]
+        t = t[(np.diff(w.tiles) >= 5) & (t + 5 <= m.n_envs)]
+        tj, tc, ta, ns, nk = (ev[t + i].astype(np.float64) for i in range(5))
+        print("   s_memtime per tile (cycles): joint slots %.0f  contact sub-slots %.0f  loop %.0f | ticks %.0f  sub-slots %.0f -> "
+              "%.0f cycles/joint slot, %.0f cycles/sub-slot" % (tj.mean() * 16, tc.mean() * 16, ta.mean() * 16, nk.mean(), ns.mean(),
+              (tj * 16 / nk).mean(), (tc * 16 / np.maximum(ns, 1)).mean()))
+    subslot_stats(w, m)
     w.close()
