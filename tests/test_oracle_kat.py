@@ -355,10 +355,12 @@ def test_time_of_impact_analytic_drop(oracle):
     # never gets within the target distance: separated, t = tMax
     state, t = oracle.time_of_impact(edge, static, box, (0.0, 2.0, 0.0, 0.0, 1.0, 0.0))
     assert (state, t) == ("separated", 1.0)
-    # starts closer than target - tolerance: b2TimeOfImpact reports failure at t = 0 ("overlapped" only below 0 separation
-    # at the root finder's t1); Box2D then takes alpha = 1 (no TOI event) for anything but e_touching
+    # already within target + tolerance at t = 0: touching at once; core shapes overlapping at t = 0: overlapped
+    # (Box2D takes alpha = 1, i.e. no TOI event, for every state but e_touching)
     state, t = oracle.time_of_impact(edge, static, box, (0.0, 0.401, 0.0, 0.0, 0.0, 0.0))
-    assert state in ("failed", "overlapped") and t == 0.0
+    assert (state, t) == ("touching", 0.0)
+    state, t = oracle.time_of_impact(edge, static, box, (0.0, 0.39, 0.0, 0.0, 0.0, 0.0))
+    assert (state, t) == ("overlapped", 0.0)
     # a circle: proxy radius r + polygonRadius, same rule
     r = 0.25
     target_c = max(slop, (r + 2 * slop) - 3 * slop)
@@ -387,11 +389,12 @@ def test_manifold_polygon_polygon_and_polygon_circle(oracle):
     assert pts == [pytest.approx((-0.25, -0.25)), pytest.approx((0.25, -0.25))]
     ids = sorted((k & 0xff, (k >> 8) & 0xff, (k >> 16) & 0xff, (k >> 24) & 0xff) for k in m["keys"])
     assert ids == [(2, 0, 1, 0), (2, 1, 1, 0)]          # (indexA = face 2, indexB = vertex, typeA face, typeB vertex)
-    # B hanging over A's right end: the clip against the side planes cuts at x = 1 -> one point is A's corner
+    # B hanging over A's right end: the side planes sit totalRadius = 2 * polygonRadius = 0.02 beyond A's corners
+    # (sideOffset = dot(tangent, v) + totalRadius), so the clip cuts at x = 1.02
     m = oracle.collide(big, (0, 0, 0), small, (1.1, 0.745, 0.0))
     assert (m["type"], m["count"]) == (1, 2)
     xs = sorted(float(p[0]) for p in m["points"])
-    assert xs[0] == pytest.approx(-0.25) and xs[1] == pytest.approx(-0.1, abs=1e-6)   # x = 1.0 in B's frame
+    assert xs[0] == pytest.approx(-0.25) and xs[1] == pytest.approx(-0.08, abs=1e-6)  # x = 1.02 in B's frame
     # separated by more than the radii: no points
     assert oracle.collide(big, (0, 0, 0), small, (0.0, 0.80, 0.0))["count"] == 0
     # B beside A (face-face on A's +x face = index 1)
@@ -446,8 +449,9 @@ def test_block_solver_four_lcp_cases(oracle):
     K = inv_m + inv_i * np.outer(rn, rn)
     seen = set()
     for v, w, a in (((0.0, -1.0), 0.0, (0.0, 0.0)),      # falling flat: both points            -> case 1
-                    ((0.0, -1.0), 3.0, (0.0, 0.0)),      # falling, spinning ccw: left corner    -> case 2
-                    ((0.0, -1.0), -3.0, (0.0, 0.0)),     # spinning cw: right corner             -> case 3
+                    ((0.0, -1.0), 10.0, (0.0, 0.0)),     # falling, spinning fast ccw: left corner  -> case 2
+                    ((0.0, -1.0), -10.0, (0.0, 0.0)),    # spinning cw: right corner                -> case 3
+                    ((0.0, -1.0), 3.0, (0.0, 0.0)),      # slow spin: both corners still push            -> case 1
                     ((0.0, 2.0), 0.0, (0.3, 0.3)),       # moving up with stored impulse: release -> case 4
                     ((0.0, -0.2), 0.5, (0.1, 0.4))):
         vn = np.array([v[1] + w * pts[0][0], v[1] + w * pts[1][0]])   # n . (v + w x r), r = (+-hx, -hy)
@@ -462,7 +466,7 @@ def test_block_solver_four_lcp_cases(oracle):
         # complementarity of the result
         vn_after = np.array([vo[1] + wo * pts[0][0], vo[1] + wo * pts[1][0]])
         assert (vn_after >= -1e-5).all() and abs(float(vn_after @ x)) < 1e-5
-    assert seen == {1, 2, 3, 4}
+    assert seen == {1, 2, 3, 4}      # (K is positive definite: one of the four always applies)
     # ill-conditioned K (points almost coincident): the solver drops to one point
     _, _, _, _, count = oracle.contact_solve(normal, [(0.0, 0.0), (1e-4, 0.0)], cB, inv_m, inv_i, 0.0, (0.0, -1.0), 0.0)
     assert count == 1
