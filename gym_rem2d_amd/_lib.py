@@ -118,6 +118,7 @@ def lib():
                                     C.POINTER(C.c_int32)]
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if L.rem2d_abi_version() != 3:
         raise Rem2dError("librem2d.so ABI version mismatch")
     _lib = L

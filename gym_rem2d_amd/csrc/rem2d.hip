@@ -107,6 +107,11 @@ struct rem2d_world {
     // region), recorded by the step calls, read back by rem2d_world_kernel_time_ms
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool;
     int evUsed;
+    // second bracket: all kernels of one env-step (pre .. toi_heavy) of the tile pipeline
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evPoolStep;
+    int evUsedStep;
+    double accumMsStep;
+    int64_t launchesStep;
 };
 
 // Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
@@ -173,6 +178,9 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->haveTerrain = w->haveReset = false;
     w->timing = false;
     w->evUsed = 0;
+    w->evUsedStep = 0;
+    w->accumMsStep = 0.0;
+    w->launchesStep = 0;
     w->accumMs = 0.0;
     w->launches = 0;
     bind_state(w);
@@ -314,14 +322,25 @@ static void drain_timing(rem2d_world *w) {
         }
     }
     w->evUsed = 0;
+    for (int i = 0; i < w->evUsedStep; ++i) {
+        auto &p = w->evPoolStep[i];
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            w->accumMsStep += ms;
+            w->launchesStep += 1;
+        }
+    }
+    w->evUsedStep = 0;
 }
 static void free_timing(rem2d_world *w) {
-    for (auto &p : w->evPool) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+    for (auto *pool : {&w->evPool, &w->evPoolStep}) {
+        for (auto &p : *pool) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        pool->clear();
     }
-    w->evPool.clear();
-    w->evUsed = 0;
+    w->evUsed = w->evUsedStep = 0;
 }
 // first event of the next free pair, or nullptr when timing is off / the pool is used up (those launches go untimed)
 static bool timing_begin(rem2d_world *w, hipStream_t st) {
@@ -546,6 +565,8 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     V.dbg = v4dbg;
     const dim3 grid(blocks), block(WAVE);
     for (int l = 0; l < n_steps; ++l) {
+        const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
+                               hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
         hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
         const bool timed = timing_begin(w0, st);
         switch (tile_shape_id()) {
@@ -559,6 +580,10 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         if (continuous) {
             hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
             hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
+        }
+        if (timedStep) {
+            (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
+            w0->evUsedStep += 1;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -774,6 +799,16 @@ extern "C" int rem2d_world_enable_timing(rem2d_world *w, int32_t on) {
             }
             w->evPool.emplace_back(a, b);
         }
+        while (w->evPoolStep.size() < want) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(hipEventCreate(&a));
+            hipError_t e = hipEventCreate(&b);
+            if (e != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return fail(REM2D_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+            }
+            w->evPoolStep.emplace_back(a, b);
+        }
     }
     w->timing = on != 0;
     return REM2D_OK;
@@ -786,5 +821,15 @@ extern "C" int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int6
     if (launches) *launches = w->launches;
     w->accumMs = 0.0;
     w->launches = 0;
+    return REM2D_OK;
+}
+extern "C" int rem2d_world_step_time_ms(rem2d_world *w, double *total_ms, int64_t *steps) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    drain_timing(w);
+    if (total_ms) *total_ms = w->accumMsStep;
+    if (steps) *steps = w->launchesStep;
+    w->accumMsStep = 0.0;
+    w->launchesStep = 0;
     return REM2D_OK;
 }

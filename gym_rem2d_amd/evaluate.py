@@ -55,9 +55,37 @@ def evaluate(individual, EVALUATION_STEPS=10000, HEADLESS=True, INTERVAL=100, EN
     return fitness
 
 
-def run_episode(env, max_steps=EPISODE_CAP, chunk=100):
+class SolverOverflow(_lib.Rem2dError):
+    """A creature ran out of engine capacity during an episode, so its trajectory is NOT what the reference's Box2D
+    computes: more than REM2D_SOLVER_SLOTS touching contacts on one body (the extra manifold was left out of the solver)
+    or more than REM2D_CONTACT_SLOTS broadphase pairs on one body (the extra pair was never created).
+    ``indices`` are the affected population indices, ``codes`` their REM2D_ERR_* bits."""
+
+    def __init__(self, indices, codes):
+        self.indices, self.codes = indices, codes
+        super().__init__("%d creature(s) overflowed the solver / pair slots (first: %s, REM2D_ERR bits %s); their fitness "
+                         "is not the reference's" % (len(indices), indices[:8], sorted(set(codes))))
+
+
+def check_errors(env, on_error="raise"):
+    """Read the per-creature engine error bits of a BatchedModular2D (REM2D_ERR_PAIR_OVERFLOW / _SOLVER_OVERFLOW).
+    on_error: "raise" -> SolverOverflow; "warn" -> warnings.warn and return the mask; "ignore" -> return the mask."""
+    err = env.errors()
+    bad = err != 0
+    if on_error != "ignore" and bool(bad.any()):
+        idx = torch.nonzero(bad).flatten().cpu().tolist()
+        codes = err[bad].cpu().tolist()
+        if on_error == "raise":
+            raise SolverOverflow(idx, codes)
+        import warnings
+        warnings.warn(str(SolverOverflow(idx, codes)))
+    return bad
+
+
+def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="raise"):
     """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
-    Returns fitness[N] (float64 tensor on the env's device)."""
+    Returns fitness[N] (float64 tensor on the env's device).  Engine overflows (see SolverOverflow) are not silent:
+    by default they raise once the episode is over."""
     done_steps = 0
     while done_steps < max_steps:
         n = min(chunk, max_steps - done_steps)
@@ -65,12 +93,15 @@ def run_episode(env, max_steps=EPISODE_CAP, chunk=100):
         done_steps += n
         if bool((env.frozen != 0).all()):
             break
+    check_errors(env, on_error)
     return env.fitness.clone()
 
 
-def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, workers=None, **env_kw):
+def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, workers=None, on_error="raise",
+                        **env_kw):
     """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats.
-    The genotype -> phenotype step runs on ``workers`` host processes (encode.encode_population)."""
+    The genotype -> phenotype step runs on ``workers`` host processes (encode.encode_population).
+    on_error: what to do when a creature overflowed the engine's contact capacity ("raise" | "warn" | "ignore")."""
     from .encode import encode_population
     from .env import BatchedModular2D
     own = env is None
@@ -88,7 +119,7 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
     else:
         batches = encode_population(individuals, tree_depth, workers)
     env._upload(batches, len(individuals))
-    fit = run_episode(env, max_steps).cpu().tolist()
+    fit = run_episode(env, max_steps, on_error=on_error).cpu().tolist()
     if own:
         env.close()
     return fit
@@ -102,24 +133,26 @@ def shard_range(n, rank, world_size):
 
 
 def all_gather_fitness(local, n_total, group=None):
-    """One all_gather of fp32 fitness scalars: [per] -> [n_total] on every rank.  `local` is
-    padded to ceil(n/W) so that the collective is a single equal-sized all_gather_into_tensor."""
+    """One all_gather of float64 fitness scalars: [per] -> [n_total] on every rank.  `local` is padded to ceil(n/W) so
+    that the collective is a single equal-sized all_gather_into_tensor.  float64 like the reference's python floats
+    (REM2D_main.py:372-375 compares ``reward + (10000 - i) / 10000`` in doubles): a sharded and a single-GPU run return
+    the same values, so tournament winners cannot depend on the world size.  8 MiB at 1 M individuals."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = math.ceil(n_total / world)
-    buf = torch.zeros(per, dtype=torch.float32, device=local.device)
-    buf[:local.numel()] = local.to(torch.float32)
-    out = torch.empty(per * world, dtype=torch.float32, device=local.device)
+    buf = torch.zeros(per, dtype=torch.float64, device=local.device)
+    buf[:local.numel()] = local.to(torch.float64)
+    out = torch.empty(per * world, dtype=torch.float64, device=local.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return out[:n_total]
 
 
 def evaluate_population_sharded(n_total, local_eval, group=None, device=None):
     """Shard [0, n_total) over the job's ranks, evaluate the local block with
-    ``local_eval(lo, hi) -> tensor[hi-lo]`` and all-gather.  Returns fitness[n_total] (fp32)."""
+    ``local_eval(lo, hi) -> tensor[hi-lo]`` and all-gather.  Returns fitness[n_total] (float64)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_total, rank, world)
     local = local_eval(lo, hi)
-    local = torch.as_tensor(local, dtype=torch.float32, device=device if device is not None else None)
+    local = torch.as_tensor(local, dtype=torch.float64, device=device if device is not None else None)
     return all_gather_fitness(local, n_total, group)

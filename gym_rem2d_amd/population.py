@@ -205,7 +205,7 @@ def sharded_evaluator(local_eval, group=None, device=None):
     """evaluate(population) for a torch.distributed job (one process per GPU): every rank holds the whole
     population as arrays (selection and mutation are replicated from a shared seed, so no genome ever crosses a
     rank boundary), expresses and evaluates only its contiguous block ``[lo, hi)`` with
-    ``local_eval(LSystemPopulation block) -> fitness[hi-lo]`` and the ranks exchange one all-gather of fp32
+    ``local_eval(LSystemPopulation block) -> fitness[hi-lo]`` and the ranks exchange one all-gather of float64
     fitness (REM2D_main.py:256-267 pool.map)."""
     import torch
     import torch.distributed as dist
@@ -214,8 +214,8 @@ def sharded_evaluator(local_eval, group=None, device=None):
     def evaluate(pop):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         lo, hi = shard_range(len(pop), rank, world)
-        local = local_eval(pop.select(np.arange(lo, hi))) if hi > lo else np.zeros(0, dtype=np.float32)
-        local = torch.as_tensor(np.asarray(local, dtype=np.float32), device=device)
+        local = local_eval(pop.select(np.arange(lo, hi))) if hi > lo else np.zeros(0, dtype=np.float64)
+        local = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
         return all_gather_fitness(local, len(pop), group).cpu().numpy().astype(np.float64)
     return evaluate
 

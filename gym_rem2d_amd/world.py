@@ -116,6 +116,12 @@ class BatchedWorld:
     def enable_timing(self, on=True):
         _lib.check(_lib.lib().rem2d_world_enable_timing(self.h, 1 if on else 0))
 
+    def step_time_ms(self):
+        """(device ms, steps) of the whole kernel sequence of the env-steps since the last call (tile pipeline)."""
+        t, n = C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().rem2d_world_step_time_ms(self.h, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
     def kernel_time_ms(self):
         t, n = C.c_double(), C.c_int64()
         _lib.check(_lib.lib().rem2d_world_kernel_time_ms(self.h, C.byref(t), C.byref(n)))

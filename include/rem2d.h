@@ -209,6 +209,9 @@ int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes,
 /* Average device time of the step kernel over the launches since the last call, measured
  * with HIP events on the launch stream (bench.py's roofline leg).  Synchronises. */
 int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int64_t *launches);
+/* The same for the whole kernel sequence of one env-step (pre, velocity, post, TOI scan, TOI solve) of the tile pipeline:
+ * device time between the first kernel's start and the last kernel's end, summed over the steps since the last call. */
+int rem2d_world_step_time_ms(rem2d_world *w, double *total_ms, int64_t *steps);
 /* on = 0: off; on = 1: on, room for 4096 timed launches between two read-backs; on > 1: room for `on` launches.  The
  * event pairs are created here, not inside the step calls. */
 int rem2d_world_enable_timing(rem2d_world *w, int32_t on);

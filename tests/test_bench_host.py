@@ -1,0 +1,63 @@
+"""Host-side pieces of bench.py that need no GPU: the self-launcher's command line and the CPU-baseline leg."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_launcher_command(monkeypatch):
+    import subprocess
+    import bench
+    seen = {}
+
+    class Done(Exception):
+        pass
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+
+        class P:
+            returncode = 0
+            stdout = 'noise\n{"n_gpus": 2}\n'
+        return P()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.setattr(sys, "exit", lambda code=0: (_ for _ in ()).throw(Done(code)))
+    ap_args = type("A", (), {"gpus": 2})()
+    try:
+        bench.launch_ranks(ap_args)
+    except Done as e:
+        assert e.args[0] == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_cpu_baseline_times_the_gpu_legs_window(oracle):
+    """The oracle leg runs ONE batch over all lane buckets, over the step window [settle, settle + window) -- not the
+    free fall right after reset -- and reports all-thread and one-thread rates."""
+    import bench
+    from gym_rem2d_amd import make_terrain, synthetic
+    from gym_rem2d_amd.compiler import Morphology, lanes_for
+    groups = {}
+    for s in synthetic.lsystem_specs(range(48)):
+        groups.setdefault(lanes_for(s.n_bodies), []).append(s)
+    morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
+    cb = bench.cpu_baseline(morphs, make_terrain(4, flat=True), 1, settle=30, window=25, budget_s=5.0)
+    assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] == (os.cpu_count() or 1)
+    assert cb["value"] > 0 and cb["value_1thread"] > 0
+    assert "steps [30, " in cb["sample"] and "48 creatures" in cb["sample"]
+    json.dumps(cb)
+    # the re-laid-out batch is the same physics: 16-lane repack of a 4-lane bucket gives the oracle the same bodies
+    m = morphs[0]
+    xs, ys, _ = make_terrain(4, flat=True).f32()
+    ot = oracle.Terrain(xs, ys, None, make_terrain(4, flat=True).friction)
+    a = oracle.batch_run(ot, m.as_dict(), 40, n_threads=2, flags=1)["bodies"]
+    b = oracle.batch_run(ot, bench._repack(m, 16), 40, n_threads=2, flags=1)["bodies"]
+    assert np.array_equal(a, b[:, :m.lanes]) and not b[:, m.lanes:].any()

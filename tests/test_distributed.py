@@ -66,10 +66,11 @@ def test_sharded_evaluation_gloo(tmp_path, oracle):
     xs, ys, _ = terrain.f32()
     ot = oracle.Terrain(xs, ys)
     morph = Morphology.from_specs(synthetic.lsystem_specs(range(n_total)), 32)
-    ref = oracle.batch_run(ot, morph.as_dict(), steps, n_threads=2)["fitness"].astype(np.float32)
+    ref = oracle.batch_run(ot, morph.as_dict(), steps, n_threads=2)["fitness"]
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "fit%d.npy" % r))
-        assert got.shape == (n_total,) and np.array_equal(got, ref)
+        # float64 end to end: the gathered values are the evaluators' doubles, bit for bit (REM2D_main.py:372-375)
+        assert got.dtype == np.float64 and got.shape == (n_total,) and np.array_equal(got, ref)
 
 
 def _ea_worker(rank, world, port, out_dir):

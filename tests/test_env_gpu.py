@@ -173,3 +173,54 @@ def test_bench_json_contract(need_gpu):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (torch.distributed.run as a child) and
+    reports n_gpus = 2; on a one-GPU box the ranks share the GPU and the fitness all-gather goes over gloo.  A rank
+    count that contradicts the launcher's WORLD_SIZE is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--envs", "512", "--settle", "5", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    assert d["metric"].startswith("env steps/sec (whole node) at 1 024 parallel creatures")
+    assert d["config"]["envs_per_gpu"] == 512 and d["config"]["solver_errors"] == 0
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
+                         text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_solver_overflow_is_not_silent(need_gpu):
+    """A body resting on more than REM2D_SOLVER_SLOTS (6) terrain edges loses a manifold in the solver: the evaluators
+    raise (or warn) instead of handing a wrong fitness to selection (Modular2DEnv.py:634 would solve all of them)."""
+    import pytest
+    import torch
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import SolverOverflow, check_errors, run_episode
+    m = synthetic.chain_population(4, 2, "left")
+    hx = m.arrays["hx"].reshape(4, m.lanes)
+    hy = m.arrays["hy"].reshape(4, m.lanes)
+    ang = m.arrays["angle"].reshape(4, m.lanes)
+    hx[2, 0], hy[2, 0], ang[2, 0] = 0.1, 2.2, np.float32(np.pi / 2)   # creature 2: a 4.4 m plank lying across ~9 edges
+    env = BatchedModular2D(flat=True)
+    env.reset_morphology(m)
+    with pytest.raises(SolverOverflow) as ei:
+        run_episode(env, max_steps=150)
+    assert ei.value.indices == [2] and ei.value.codes[0] & _lib.ERR_SOLVER_OVERFLOW
+    env.reset_morphology(m)
+    with pytest.warns(UserWarning):
+        fit = run_episode(env, max_steps=150, on_error="warn")
+    assert fit.shape == (4,) and bool(check_errors(env, "ignore")[2]) and int(check_errors(env, "ignore").sum()) == 1
+    env.close()
+    torch.cuda.synchronize()
