@@ -72,7 +72,6 @@ enum { CF_VERTEX = 0, CF_FACE = 1 };
 #include "rem2d_position.h"
 #include "rem2d_kernels.h"
 #include "rem2d_pipeline.h"
-#include "rem2d_vel3.h"
 #include "rem2d_vel4.h"
 #include "rem2d_diversity.h"
 
@@ -493,31 +492,12 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
     return REM2D_OK;
 }
 
-// Lanes per creature (Q) and creatures per wavefront (cw) of rem2d_vel3_kernel.  Q = K/2 always suffices (the
-// joints of one schedule phase of a creature are a matching of its tree); REM2D_VEL3_Q overrides it for
-// populations whose largest phase class is known to be smaller (a too small Q is reported as SOLVER_OVERFLOW).
-static Vel3Args vel3_args(int lanes, int vel_iters, float dt, float friction) {
-    static const int qEnv = getenv("REM2D_VEL3_Q") ? atoi(getenv("REM2D_VEL3_Q")) : 0;
-    Vel3Args A;
-    A.K = lanes;
-    A.Q = lanes / 2 > 0 ? lanes / 2 : 1;
-    if (qEnv > 0 && qEnv < A.Q) A.Q = qEnv;
-    int cw = WAVE / A.Q;
-    if (cw * lanes > V3_MAX_BODIES) cw = V3_MAX_BODIES / lanes;
-    // keep whole 64-lane passes: cw * K must be a multiple of 64
-    while (cw > 1 && (cw * lanes) % WAVE != 0) --cw;
-    A.cw = cw;
-    A.velIters = vel_iters;
-    A.dt = dt;
-    A.friction = friction;
-    return A;
-}
-
-// REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = fused
-// rem2d_step_kernel, 1 = split pipeline with the 4-wave rem2d_vel_kernel, 2 = rem2d_vel3_kernel (single world only).
+// REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = the fused
+// rem2d_step_kernel of round 1 (one body per lane for the whole step) -- kept as an independently written second
+// formulation that the parity suite runs against the same oracle.
 static int pipeline_mode() {
     static const int mode = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 3;
-    return mode;
+    return mode == 0 ? 0 : 3;
 }
 
 // The tile pipeline for one or several worlds (lane buckets) in one grid per kernel: pre and post run one body per
@@ -597,24 +577,18 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
+    if (pipeline_mode() == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    // ---- fused kernel: n_steps env-steps per launch in discrete mode, one per launch when the TOI kernels follow ----
     const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    const int pipelineEnv = pipeline_mode();
-    if (pipelineEnv == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
-    const bool split = pipelineEnv == 1 || pipelineEnv == 2; // 2: the wave-level velocity kernel rem2d_vel3_kernel
     StepArgs A;
-    A.nSteps = (continuous || split) ? 1 : n_steps;
+    A.nSteps = continuous ? 1 : n_steps;
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
     A.defer = continuous ? 1 : 0;
     dim3 grid((unsigned)w->L.Lp / WAVE), block(WAVE);
     hipStream_t st = (hipStream_t)stream;
-    const int launches = (continuous || split) ? n_steps : 1;
-    for (int l = 0; l < launches; ++l) {
-        // timing brackets the dominant kernel only (bench.py's roofline leg): the fused step kernel, or the
-        // velocity kernel of the split pipeline
-        bool timed = false;
-        if (split) {
+    const int launches = continuous ? n_steps : 1;
 #define LAUNCH_K(NAME, KK) hipLaunchKernelGGL((NAME<KK>), grid, block, 0, st, w->S, w->T, A)
 #define LAUNCH_BY_LANES(NAME)                  \
     switch (w->cfg.lanes) {                    \
@@ -625,42 +599,10 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     case 32: LAUNCH_K(NAME, 32); break;        \
     default: LAUNCH_K(NAME, 64); break;        \
     }
-            LAUNCH_BY_LANES(rem2d_pre_kernel);
-            VelArgs V;
-            V.K = w->cfg.lanes;
-            V.velIters = vel_iters;
-            V.dt = dt;
-            V.friction = w->T.friction;
-            timed = timing_begin(w, st);
-            if (pipelineEnv == 2) {
-                Vel3Args V3 = vel3_args(w->cfg.lanes, vel_iters, dt, w->T.friction);
-                const unsigned nb = (unsigned)(V3.cw * V3.K);
-                hipLaunchKernelGGL(rem2d_vel3_kernel, dim3(((unsigned)w->L.Lp + nb - 1) / nb), dim3(WAVE), 0, st, w->S, V3);
-            } else {
-                hipLaunchKernelGGL(rem2d_vel_kernel, dim3(((unsigned)w->L.Lp + VEL_THREADS - 1) / VEL_THREADS), dim3(VEL_THREADS),
-                                   0, st, w->S, V);
-            }
-            if (timed) timing_end(w, st);
-            LAUNCH_BY_LANES(rem2d_post_kernel);
-        } else {
-            timed = timing_begin(w, st);
-            // 3 waves/SIMD only when the grid can fill them (> 2 waves per SIMD on 256 CUs x 4 SIMDs)
-            static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
-            const bool three = forced ? forced == 3 : grid.x > 2u * 1024u * 2u;
-#define LAUNCH_STEP(KK)                                                                              \
-    if (three) hipLaunchKernelGGL((rem2d_step_kernel<KK, 3>), grid, block, 0, st, w->S, w->T, A);  \
-    else hipLaunchKernelGGL((rem2d_step_kernel<KK, 2>), grid, block, 0, st, w->S, w->T, A)
-            switch (w->cfg.lanes) {
-            case 2: LAUNCH_STEP(2); break;
-            case 4: LAUNCH_STEP(4); break;
-            case 8: LAUNCH_STEP(8); break;
-            case 16: LAUNCH_STEP(16); break;
-            case 32: LAUNCH_STEP(32); break;
-            default: LAUNCH_STEP(64); break;
-            }
-#undef LAUNCH_STEP
-            if (timed) timing_end(w, st);
-        }
+    for (int l = 0; l < launches; ++l) {
+        const bool timed = timing_begin(w, st); // the dominant kernel only (bench.py's roofline leg)
+        LAUNCH_BY_LANES(rem2d_step_kernel);
+        if (timed) timing_end(w, st);
         if (continuous) {
             LAUNCH_BY_LANES(rem2d_toi_scan_kernel);
             LAUNCH_BY_LANES(rem2d_toi_heavy_kernel);
@@ -677,9 +619,6 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     if (n_worlds == 1) return rem2d_world_step_ex(ws[0], n_steps, dt, vel_iters, pos_iters, stream);
     if (n_worlds > REM2D_MAX_WORLDS_PER_STEP) return fail(REM2D_E_INVALID, "too many worlds for one launch");
     static_assert(REM2D_MAX_WORLDS_PER_STEP == REM2D_MAX_BATCH, "batch size");
-    Batch B;
-    memset(&B, 0, sizeof(B));
-    unsigned blocks = 0;
     for (int i = 0; i < n_worlds; ++i) {
         rem2d_world *w = ws[i];
         if (!w) return fail(REM2D_E_INVALID, "world is NULL");
@@ -688,6 +627,16 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
         if (w->cfg.device != ws[0]->cfg.device) return fail(REM2D_E_INVALID, "worlds of one launch must share the device");
         if ((w->cfg.flags & REM2D_FLAG_CONTINUOUS) != (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS))
             return fail(REM2D_E_INVALID, "worlds of one launch must agree on REM2D_FLAG_CONTINUOUS");
+    }
+    if (n_steps <= 0) return REM2D_OK;
+    rem2d_world *w0 = ws[0];
+    HIP_TRY(hipSetDevice(w0->cfg.device));
+    if (pipeline_mode() == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    unsigned blocks = 0;
+    for (int i = 0; i < n_worlds; ++i) {
+        rem2d_world *w = ws[i];
         B.S[i] = w->S;
         B.T[i] = w->T;
         B.lanes[i] = w->cfg.lanes;
@@ -695,10 +644,6 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
         B.blockEnd[i] = blocks;
     }
     B.n = n_worlds;
-    if (n_steps <= 0) return REM2D_OK;
-    rem2d_world *w0 = ws[0];
-    HIP_TRY(hipSetDevice(w0->cfg.device));
-    if (pipeline_mode() == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
     const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     StepArgs A;
     A.nSteps = continuous ? 1 : n_steps;
@@ -708,41 +653,10 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     A.defer = continuous ? 1 : 0;
     dim3 grid(blocks), block(WAVE);
     hipStream_t st = (hipStream_t)stream;
-    // the merged kernel's 3-waves/SIMD build spills in every lane-count variant; 2 waves/SIMD measured faster
-    static const int forced = getenv("REM2D_WAVES_PER_SIMD") ? atoi(getenv("REM2D_WAVES_PER_SIMD")) : 0;
-    const bool three = forced == 3;
-    const bool split = pipeline_mode() == 1;
-    if (split) A.nSteps = 1;
-    VelBatch VB;
-    memset(&VB, 0, sizeof(VB));
-    unsigned vblocks = 0;
-    for (int i = 0; i < n_worlds; ++i) {
-        VB.S[i] = ws[i]->S;
-        VB.lanes[i] = ws[i]->cfg.lanes;
-        vblocks += ((unsigned)ws[i]->L.Lp + VEL_THREADS - 1) / VEL_THREADS;
-        VB.blockEnd[i] = vblocks;
-    }
-    VB.n = n_worlds;
-    VelArgs V;
-    V.K = 0;
-    V.velIters = vel_iters;
-    V.dt = dt;
-    V.friction = w0->T.friction;
-    for (int i = 1; i < n_worlds; ++i)
-        if (split && ws[i]->T.friction != w0->T.friction)
-            return fail(REM2D_E_INVALID, "worlds of one launch must share the terrain friction");
-    const int launches = (continuous || split) ? n_steps : 1;
+    const int launches = continuous ? n_steps : 1;
     for (int l = 0; l < launches; ++l) {
         const bool timed = timing_begin(w0, st);
-        if (split) {
-            hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
-            hipLaunchKernelGGL(rem2d_vel_multi_kernel, dim3(vblocks), dim3(VEL_THREADS), 0, st, VB, V);
-            hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
-        } else if (three) {
-            hipLaunchKernelGGL(rem2d_step_multi_kernel<3>, grid, block, 0, st, B, A);
-        } else {
-            hipLaunchKernelGGL(rem2d_step_multi_kernel<2>, grid, block, 0, st, B, A);
-        }
+        hipLaunchKernelGGL(rem2d_step_multi_kernel, grid, block, 0, st, B, A);
         if (timed) timing_end(w0, st);
         if (continuous) {
             hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);

@@ -35,8 +35,7 @@ struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TO
 // joint effective-mass terms and impulses, KR contact constraints); everything else (pose
 // history, shape, fat AABB, anchors, controller, per-creature bookkeeping) is re-read from
 // HBM/L2 at its point of use once per step, so that the kernel fits two waves per SIMD.
-// W = waves per SIMD the register allocation targets: 2 (238 VGPRs, no spills) or 3 (168 VGPRs, ~95 spilled
-// outside the velocity loop); 3 pays off only when the launch has enough waves to fill the extra slots.
+// Two waves per SIMD (238 VGPRs, no spills); a 3-waves build (168 VGPRs) spilled ~95 registers and was not faster.
 template <int K>
 DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
     // psh.mbox: velocity mailbox of the joint slots; the rest of psh: position solver
@@ -470,8 +469,8 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     }
 }
 
-template <int K, int W>
-__global__ __launch_bounds__(WAVE, W) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
+template <int K>
+__global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
     __shared__ PosShared psh;
     step_body<K>(S, T, A, blockIdx.x, psh);
 }
@@ -503,8 +502,7 @@ DEV int batch_find(const Batch &B, unsigned &block) {
     case 32: BODY<32>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break; \
     default: BODY<64>(B.S[b], B.T[b], A, block, ##__VA_ARGS__); break; \
     }
-template <int W>
-__global__ __launch_bounds__(WAVE, W) void rem2d_step_multi_kernel(Batch B, StepArgs A) {
+__global__ __launch_bounds__(WAVE, 2) void rem2d_step_multi_kernel(Batch B, StepArgs A) {
     __shared__ PosShared psh;
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);

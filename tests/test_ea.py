@@ -95,3 +95,48 @@ def test_parallel_encoder_equals_serial_path():
         for k in mr.arrays:
             assert np.array_equal(m1.arrays[k], mr.arrays[k]) and np.array_equal(m2.arrays[k], mr.arrays[k])
         assert np.array_equal(m1.n_bodies, mr.n_bodies) and np.array_equal(m2.n_bodies, mr.n_bodies)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding", ["lsystem", "direct"])
+def test_generation_on_gpu_equals_generation_with_the_oracle(encoding, oracle):
+    """(f2) The EA generation of REM2D_main.py:280-298 -- tournament-4, clone, mutate, evaluate -- run twice from the
+    same seed: once with the batched GPU episode as the evaluator, once with the CPU oracle.  Fitness feeds selection,
+    so any difference in any fitness bit would change the offspring of the next generation: populations, fitness
+    lists and per-generation statistics must be identical."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gym_rem2d_amd import _lib, make_terrain
+    from gym_rem2d_amd.encode import encode_population
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import evaluate_population
+    steps = 500
+    cfg = ea.make_config(population_size=40, encoding=encoding, morphmutation_prob=0.2, mutation_prob=0.2)
+    depth = int(cfg["morphology"]["max_depth"])
+    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
+
+    def gpu_eval(inds):
+        return evaluate_population(inds, tree_depth=depth, env=env, max_steps=steps)
+
+    terrain = make_terrain(4)
+    xs, ys, _ = terrain.f32()
+    ot = oracle.Terrain(xs, ys, None, terrain.friction)
+
+    def oracle_eval(inds):
+        out = [0.0] * len(inds)
+        for m, idx in encode_population(inds, depth, workers=1):
+            fit = oracle.batch_run(ot, m.as_dict(), steps, n_threads=8, flags=oracle.FLAG_CONTINUOUS)["fitness"]
+            for e, f in zip(idx, fit):
+                out[e] = float(f)
+        return out
+
+    pop_g, hist_g = ea.run_ea(cfg, evaluate_batch=gpu_eval, seed=21, n_generations=3, log=None)
+    pop_o, hist_o = ea.run_ea(cfg, evaluate_batch=oracle_eval, seed=21, n_generations=3, log=None)
+    env.close()
+    assert [p.fitness for p in pop_g] == [p.fitness for p in pop_o]
+    assert [h[:4] for h in hist_g] == [h[:4] for h in hist_o]
+    assert len({p.fitness for p in pop_g}) > 5 and max(p.fitness for p in pop_g) > 0
+    for a, b in zip(pop_g, pop_o):   # same genomes came out of selection + mutation
+        na, nb = a.genome.create(depth).getNodes(), b.genome.create(depth).getNodes()
+        assert [(n.index, n.parent, n.type) for n in na] == [(n.index, n.parent, n.type) for n in nb]

@@ -331,9 +331,12 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
     assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
 
 
-def test_split_pipeline_matches_committed_digests(gpu):
-    """REM2D_PIPELINE=1 (pre / constraint-lane velocity / post kernels) is read once per process, so it runs in
-    a child process: same committed digests as the fused path."""
+@pytest.mark.parametrize("variant", [{"REM2D_PIPELINE": "0"}, {"REM2D_TILE_SHAPE": "0"}, {"REM2D_TILE_SHAPE": "1"}],
+                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies"])
+def test_other_formulations_match_committed_digests(gpu, variant):
+    """The library's switches are read once per process, so every other formulation runs in a child process: the fused
+    body-per-lane kernel of round 1 (REM2D_PIPELINE=0) and the wider tile shapes of the velocity kernel (256 / 128
+    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default."""
     import json
     import os
     import subprocess
@@ -351,7 +354,7 @@ def test_split_pipeline_matches_committed_digests(gpu):
         "                         w.view('fitness').cpu().numpy())\n"
         "    w.close()\n"
         "print('DIGESTS ' + json.dumps(out))\n") % (root, os.path.join(root, "tools"))
-    env = dict(os.environ, REM2D_PIPELINE="1")
+    env = dict(os.environ, **variant)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
@@ -381,3 +384,68 @@ def test_worlds_step_argument_errors(gpu, flat_terrain):
     assert L.rem2d_worlds_step(pair, 2, 1, st) != 0 and b"set_terrain" in L.rem2d_last_error()   # c has no terrain yet
     for w in (a, b, c):
         w.close()
+
+
+def test_full_size_config4_cppn_on_hardcore_terrain(gpu, oracle):
+    """BASELINE config 4 at full size: 65 536 network-encoded creatures on the hardcore track (pits, stumps, stairs:
+    polygon-polygon / polygon-circle manifolds and TOI against static boxes), continuous physics, through the env facade
+    (lane buckets, tiles, step groups).  384 unique creatures tiled: the first tile equals the oracle in every bit,
+    every replica equals the first tile, no solver / pair overflow anywhere."""
+    import torch
+    from gym_rem2d_amd import _lib, make_terrain, synthetic
+    from gym_rem2d_amd.compiler import Morphology, lanes_for
+    from gym_rem2d_amd.env import BatchedModular2D
+    N, U, steps = 65536, 384, 150
+    specs = synthetic.cppn_specs(range(U))
+    env = BatchedModular2D(hardcore=True, flags=_lib.FLAG_CONTINUOUS)
+    env.reset_specs([specs[e % U] for e in range(N)])
+    for _ in range(steps // 50):
+        env.step(50)
+    torch.cuda.synchronize()
+    assert int(env.errors().max()) == 0
+    terrain = make_terrain(4, hardcore=True)
+    ot = oracle_terrain(oracle, terrain)
+    groups = {}
+    for e, s in enumerate(specs):
+        groups.setdefault(lanes_for(s.n_bodies), []).append(e)
+    fit = env.fitness.cpu().numpy()
+    ref_fit = np.zeros(U)
+    for k in sorted(groups):
+        m = Morphology.from_specs([specs[e] for e in groups[k]], k)
+        r = oracle.batch_run(ot, m.as_dict(), steps, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+        ref_fit[groups[k]] = r["fitness"]
+    assert np.array_equal(fit[:U], ref_fit)                         # evaluate()'s running fitness, float64, first tile
+    R = N // U
+    assert np.array_equal(fit[:R * U].reshape(R, U), np.broadcast_to(ref_fit, (R, U)))   # every full replica
+    steps_taken = env.steps.cpu().numpy()
+    assert (steps_taken == steps).all()
+    env.close()
+
+
+def test_full_size_config5_generation_share(gpu, oracle, rough_terrain):
+    """BASELINE config 5's per-GPU share: a 131 072-individual array population through the native L-system compiler,
+    lane buckets, tiles and whole episodes (evaluate()'s rule, REM2D_FLAG_SKIP_FROZEN).  A 1 % sample of the
+    individuals is re-evaluated by the oracle: identical float64 fitness; no overflow flags."""
+    import torch
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import check_errors, run_episode
+    from gym_rem2d_amd.population import LSystemPopulation
+    N, cap = 131072, 300
+    rng = np.random.default_rng(5)
+    pop = LSystemPopulation.random(N, rng, max_modules=15)
+    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
+    env._upload(pop.compile(0), N)
+    fit = run_episode(env, max_steps=cap, on_error="ignore").cpu().numpy()
+    bad = check_errors(env, "ignore").cpu().numpy()
+    env.close()
+    assert fit.shape == (N,) and np.isfinite(fit).all() and (fit > 0).mean() > 0.5
+    sample = rng.choice(N, N // 100, replace=False)
+    ot = oracle_terrain(oracle, rough_terrain)
+    ref = np.zeros(N)
+    for m, idx in pop.select(sample).compile(0):
+        r = oracle.batch_run(ot, m.as_dict(), cap, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+        ref[sample[np.asarray(idx)]] = r["fitness"]
+    ok = ~bad[sample]
+    assert ok.mean() > 0.99                                          # overflow (flagged, not silent) is rare
+    assert np.array_equal(fit[sample][ok], ref[sample][ok])
