@@ -55,6 +55,13 @@ class LsystemGenomes(C.Structure):
         "ctl_freq", "ctl_offset", "rule_n", "rule_site", "rule_ref")]
 
 
+class TreeBatch(C.Structure):
+    """rem2d_tree_batch (include/rem2d.h): host pointers, [n][max_nodes]."""
+    _fields_ = [("n", C.c_int32), ("max_nodes", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "node_count", "index", "parent", "site", "shape", "width", "height", "radius", "angle", "torque", "ctl_amp",
+        "ctl_phase", "ctl_freq", "ctl_offset")]
+
+
 class Rem2dError(RuntimeError):
     pass
 
@@ -113,6 +120,7 @@ def lib():
                                        C.c_void_p]
     L.rem2d_compile_lsystem.argtypes = [C.POINTER(LsystemGenomes), C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                         C.POINTER(Morph), C.c_void_p, C.c_int32]
+    L.rem2d_compile_trees.argtypes = [C.POINTER(TreeBatch), C.c_double, C.c_int32, C.POINTER(Morph), C.c_void_p, C.c_int32]
     L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]

@@ -258,6 +258,45 @@ static void schedule(const Creature &cr, int *rounds, int *offC, int &period) {
     }
 }
 
+// one creature -> the [creature][lane] arrays rem2d_world_reset uploads (lane = body slot; joint data on the child's lane)
+static void write_creature(const rem2d_morph *out, size_t lo, int lanes, const Creature &cr, const TreeNode *nodes, const Genome &g,
+                           float lower, float upper) {
+    int rounds[MAXN], offC[MAXN], period;
+    schedule(cr, rounds, offC, period);
+    for (int l = 0; l < lanes; ++l) {
+        const size_t i = lo + l;
+        ((int32_t *)out->shape)[i] = 0; ((int32_t *)out->parent)[i] = -1; ((int32_t *)out->jround)[i] = 0;
+        ((float *)out->hx)[i] = 0; ((float *)out->hy)[i] = 0; ((float *)out->x)[i] = 0; ((float *)out->y)[i] = 0;
+        ((float *)out->angle)[i] = 0; ((float *)out->ax)[i] = 0; ((float *)out->ay)[i] = 0;
+        ((float *)out->bx)[i] = 0; ((float *)out->by)[i] = 0; ((float *)out->torque)[i] = 0;
+        ((float *)out->lower)[i] = 0; ((float *)out->upper)[i] = 0;
+        ((double *)out->amp)[i] = 0; ((double *)out->phase)[i] = 0; ((double *)out->freq)[i] = 0;
+        ((double *)out->offset)[i] = 0; ((double *)out->istate)[i] = 0;
+    }
+    for (int b = 0; b < cr.nBodies; ++b) {
+        const size_t i = lo + b;
+        ((int32_t *)out->jround)[i] = (offC[b] << 8) | (period << 16);
+        ((int32_t *)out->shape)[i] = cr.bodies[b].shape;
+        ((float *)out->hx)[i] = (float)cr.bodies[b].hx; ((float *)out->hy)[i] = (float)cr.bodies[b].hy;
+        ((float *)out->x)[i] = (float)cr.bodies[b].x; ((float *)out->y)[i] = (float)cr.bodies[b].y;
+        ((float *)out->angle)[i] = (float)cr.bodies[b].angle;
+    }
+    for (int k = 0; k < cr.nJoints; ++k) {
+        const Joint &j = cr.joints[k];
+        const size_t i = lo + j.child;
+        const int t = nodes[j.node].type;
+        ((int32_t *)out->parent)[i] = j.parent;
+        ((int32_t *)out->jround)[i] |= rounds[k];
+        ((float *)out->ax)[i] = (float)j.ax; ((float *)out->ay)[i] = (float)j.ay;
+        ((float *)out->bx)[i] = (float)j.bx; ((float *)out->by)[i] = (float)j.by;
+        ((float *)out->torque)[i] = (float)j.torque;
+        ((float *)out->lower)[i] = lower; ((float *)out->upper)[i] = upper;
+        ((double *)out->amp)[i] = g.amp[t]; ((double *)out->phase)[i] = g.phase[t];
+        ((double *)out->freq)[i] = g.freq[t]; ((double *)out->offset)[i] = g.offset[t];
+        ((double *)out->istate)[i] = 0.0;
+    }
+}
+
 } // namespace rem2d_host
 
 extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tree_depth, int32_t max_modules,
@@ -293,41 +332,7 @@ extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tre
             Creature cr;
             build_creature(g, nodes, nNodes, terrain_height, cr);
             if (ex.overflow || cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
-            int rounds[MAXN], offC[MAXN], period;
-            schedule(cr, rounds, offC, period);
-            const size_t lo = (size_t)e * lanes;
-            for (int l = 0; l < lanes; ++l) {
-                const size_t i = lo + l;
-                ((int32_t *)out->shape)[i] = 0; ((int32_t *)out->parent)[i] = -1; ((int32_t *)out->jround)[i] = 0;
-                ((float *)out->hx)[i] = 0; ((float *)out->hy)[i] = 0; ((float *)out->x)[i] = 0; ((float *)out->y)[i] = 0;
-                ((float *)out->angle)[i] = 0; ((float *)out->ax)[i] = 0; ((float *)out->ay)[i] = 0;
-                ((float *)out->bx)[i] = 0; ((float *)out->by)[i] = 0; ((float *)out->torque)[i] = 0;
-                ((float *)out->lower)[i] = 0; ((float *)out->upper)[i] = 0;
-                ((double *)out->amp)[i] = 0; ((double *)out->phase)[i] = 0; ((double *)out->freq)[i] = 0;
-                ((double *)out->offset)[i] = 0; ((double *)out->istate)[i] = 0;
-            }
-            for (int b = 0; b < cr.nBodies; ++b) {
-                const size_t i = lo + b;
-                ((int32_t *)out->jround)[i] = (offC[b] << 8) | (period << 16);
-                ((int32_t *)out->shape)[i] = cr.bodies[b].shape;
-                ((float *)out->hx)[i] = (float)cr.bodies[b].hx; ((float *)out->hy)[i] = (float)cr.bodies[b].hy;
-                ((float *)out->x)[i] = (float)cr.bodies[b].x; ((float *)out->y)[i] = (float)cr.bodies[b].y;
-                ((float *)out->angle)[i] = (float)cr.bodies[b].angle;
-            }
-            for (int k = 0; k < cr.nJoints; ++k) {
-                const Joint &j = cr.joints[k];
-                const size_t i = lo + j.child;
-                const int t = nodes[j.node].type;
-                ((int32_t *)out->parent)[i] = j.parent;
-                ((int32_t *)out->jround)[i] |= rounds[k];
-                ((float *)out->ax)[i] = (float)j.ax; ((float *)out->ay)[i] = (float)j.ay;
-                ((float *)out->bx)[i] = (float)j.bx; ((float *)out->by)[i] = (float)j.by;
-                ((float *)out->torque)[i] = (float)j.torque;
-                ((float *)out->lower)[i] = lower; ((float *)out->upper)[i] = upper;
-                ((double *)out->amp)[i] = g.amp[t]; ((double *)out->phase)[i] = g.phase[t];
-                ((double *)out->freq)[i] = g.freq[t]; ((double *)out->offset)[i] = g.offset[t];
-                ((double *)out->istate)[i] = 0.0;
-            }
+            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
             n_bodies[e] = cr.nBodies;
         }
     };
@@ -340,6 +345,63 @@ extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tre
     }
     for (int s : status)
         if (s) return fail(REM2D_E_INVALID, "a creature has more bodies than `lanes` (n_bodies = -1 marks it)");
+    return REM2D_OK;
+}
+
+// Phenotype trees of ANY encoding (direct, network, cellular ...: whatever genome.create() returned) -> morphology.
+// The tree is given node by node in Tree.getNodes() order with each node's own module and controller parameters
+// (Direct_Encoding.py:18-27 keeps a module object per node; Network_Encoding.py:97-129 sets one per query), so the
+// "type" table of build_creature is simply the node list of that creature.
+extern "C" int rem2d_compile_trees(const rem2d_tree_batch *B, double terrain_height, int32_t lanes, const rem2d_morph *out,
+                                   int32_t *n_bodies, int32_t n_threads) {
+    using namespace rem2d_host;
+    if (!B || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (B->max_nodes <= 0 || B->max_nodes > MAXN) return fail(REM2D_E_INVALID, "max_nodes must be 1..64");
+    if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
+    const int n = B->n, M = B->max_nodes;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads > n) n_threads = n > 0 ? n : 1;
+    const float lower = (float)(-PI / 2), upper = (float)(PI / 2);
+    std::vector<int> status((size_t)(n_threads > 0 ? n_threads : 1), 0);
+    auto work = [&](int tid) {
+        const int per = (n + n_threads - 1) / n_threads;
+        const int e0 = tid * per, e1 = e0 + per < n ? e0 + per : n;
+        for (int e = e0; e < e1; ++e) {
+            const size_t r = (size_t)e * M;
+            const int nNodes = B->node_count[e];
+            if (nNodes < 0 || nNodes > M) { status[tid] = 2; n_bodies[e] = -1; continue; }
+            Genome g;
+            g.nTypes = nNodes;
+            g.shape = B->shape + r;
+            g.width = B->width + r; g.height = B->height + r; g.radius = B->radius + r; g.angle = B->angle + r;
+            g.torque = B->torque + r;
+            g.amp = B->ctl_amp + r; g.phase = B->ctl_phase + r; g.freq = B->ctl_freq + r; g.offset = B->ctl_offset + r;
+            g.ruleN = nullptr; g.ruleSite = nullptr; g.ruleRef = nullptr;
+            TreeNode nodes[MAXN];
+            for (int i = 0; i < nNodes; ++i) {
+                nodes[i].index = B->index[r + i];
+                nodes[i].parent = B->parent[r + i];
+                nodes[i].site = B->site[r + i];
+                nodes[i].type = i;
+            }
+            Creature cr;
+            build_creature(g, nodes, nNodes, terrain_height, cr);
+            if (cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
+            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
+            n_bodies[e] = cr.nBodies;
+        }
+    };
+    if (n_threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    for (int s : status) {
+        if (s == 2) return fail(REM2D_E_INVALID, "node_count out of range");
+        if (s) return fail(REM2D_E_INVALID, "a creature has more bodies than `lanes` (n_bodies = -1 marks it)");
+    }
     return REM2D_OK;
 }
 

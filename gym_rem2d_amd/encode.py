@@ -179,3 +179,87 @@ def encode_lsystem_native(individuals, tree_depth=None, n_threads=0):
         raise ValueError("genomes of one batch must share treeDepth / maxModules")
     lanes = 64 if maxm + 1 > 32 else lanes_for(maxm + 1)
     return batches_from_compiled(compile_lsystem_arrays(arrays, depth, maxm, lanes, n_threads))
+
+
+# ------------------------------------------------------------------------------------------------
+# native path for every other encoding: flatten the phenotype trees, rem2d_compile_trees does the rest
+# ------------------------------------------------------------------------------------------------
+_TREE_F64 = ("width", "height", "radius", "angle", "torque", "ctl_amp", "ctl_phase", "ctl_freq", "ctl_offset")
+_TREE_I32 = ("index", "parent", "site", "shape")
+
+
+def tree_batch_arrays(trees, module_lists=None, max_nodes=None):
+    """Flatten phenotype trees (``genome.create()`` of any encoding) into the [n][max_nodes] node tables of
+    rem2d_compile_trees: per node its index / parent / connection site and the parameters of ITS module and controller
+    (``node.module_`` where the encoding set one -- Direct_Encoding.py:18-27, Network_Encoding.py:97-129 -- else the
+    prototype ``module_list[node.type]``).  Attribute reads only: no deepcopy, no trigonometry."""
+    n = len(trees)
+    node_lists = [t.getNodes() for t in trees]
+    if max_nodes is None:
+        max_nodes = max([len(nl) for nl in node_lists] + [1])
+    a = {k: np.zeros((n, max_nodes), np.int32) for k in _TREE_I32}
+    a.update({k: np.zeros((n, max_nodes), np.float64) for k in _TREE_F64})
+    a["site"][:] = -1
+    count = np.zeros(n, np.int32)
+    idx, par, site, shape = a["index"], a["parent"], a["site"], a["shape"]
+    wid, hei, rad, ang, tor = a["width"], a["height"], a["radius"], a["angle"], a["torque"]
+    amp, pha, fre, off = a["ctl_amp"], a["ctl_phase"], a["ctl_freq"], a["ctl_offset"]
+    for e, nodes in enumerate(node_lists):
+        if len(nodes) > max_nodes:
+            raise ValueError("tree %d has %d nodes, more than max_nodes=%d" % (e, len(nodes), max_nodes))
+        ml = module_lists[e] if module_lists is not None else None
+        count[e] = len(nodes)
+        for i, nd in enumerate(nodes):
+            m = nd.module_ if nd.module_ is not None else ml[nd.type]
+            idx[e, i], par[e, i] = nd.index, nd.parent
+            con = nd.parent_connection_coordinates
+            if con is not None:
+                site[e, i] = _SITE[con.name]
+            if m.type == "SIMPLE":
+                shape[e, i], wid[e, i], hei[e, i] = 1, m.width, m.height
+            else:
+                shape[e, i], rad[e, i] = 2, m.radius
+            ang[e, i], tor[e, i] = m.angle, m.torque
+            c = nd.controller
+            if c is not None:
+                amp[e, i], pha[e, i], fre[e, i], off[e, i] = c.amplitude, c.phase, c.frequency, c.offset
+    a["node_count"] = count
+    return a
+
+
+def compile_tree_arrays(arrays, lanes, n_threads=0):
+    """rem2d_compile_trees on node tables -> Morphology with `lanes` lanes per creature."""
+    import ctypes as C
+    from . import _lib
+    from .compiler import TERRAIN_HEIGHT
+    n, M = arrays["index"].shape
+    m = Morphology(n, lanes)
+    B = _lib.TreeBatch()
+    B.n, B.max_nodes = int(n), int(M)
+    keep = []
+    for k in ("node_count",) + _TREE_I32 + _TREE_F64:
+        v = np.ascontiguousarray(arrays[k])
+        keep.append(v)
+        setattr(B, k, v.ctypes.data_as(C.c_void_p))
+    out = _lib.Morph()
+    for k in m.arrays:
+        setattr(out, k, m.arrays[k].ctypes.data_as(C.c_void_p))
+    _lib.check(_lib.lib().rem2d_compile_trees(C.byref(B), float(TERRAIN_HEIGHT), int(lanes), C.byref(out),
+                                              m.n_bodies.ctypes.data_as(C.c_void_p), int(n_threads)))
+    return m
+
+
+def encode_trees_native(individuals, tree_depth=None, n_threads=0):
+    """Same result as encode_population for any encoding: ``genome.create()`` in Python (for the direct encoding that
+    is handing out the tree the genome already is), everything after it -- create_robot, connection sites, joint
+    anchors, island order, schedule, SoA packing -- natively on all host threads."""
+    if not individuals:
+        return []
+    trees, mls = [], []
+    for ind in individuals:
+        trees.append(ind.genome.create(tree_depth if tree_depth is not None else ind.tree_depth))
+        mls.append(ind.genome.moduleList)
+    arrays = tree_batch_arrays(trees, mls)
+    M = arrays["index"].shape[1]
+    lanes = 64 if M > 32 else lanes_for(M)
+    return batches_from_compiled(compile_tree_arrays(arrays, lanes, n_threads))

@@ -117,7 +117,9 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
         from .encode import encode_lsystem_native
         batches = encode_lsystem_native(individuals, n_threads=workers or 0)
     else:
-        batches = encode_population(individuals, tree_depth, workers)
+        # every other encoding: python hands out the phenotype trees, the native compiler builds the creatures
+        from .encode import encode_trees_native
+        batches = encode_trees_native(individuals, tree_depth, n_threads=workers or 0)
     env._upload(batches, len(individuals))
     fit = run_episode(env, max_steps, on_error=on_error).cpu().tolist()
     if own:

@@ -192,6 +192,22 @@ int rem2d_compile_lsystem(const rem2d_lsystem_genomes *genomes, int32_t tree_dep
                           double terrain_height, int32_t lanes, const rem2d_morph *out, int32_t *n_bodies,
                           int32_t n_threads);
 
+/* The same for phenotype trees of any encoding, node by node: Encodings/Direct_Encoding.py:18-27 (the genome IS the
+ * tree, one module object per node), Network_Encoding.py:97-129,171-206 (one module + controller per network query),
+ * i.e. whatever genome.create() returned, flattened in Tree.getNodes() order.  HOST pointers, [n][max_nodes]. */
+typedef struct {
+    int32_t n, max_nodes;                     /* creatures, nodes per creature (<= 64) */
+    const int32_t *node_count;                /* [n] nodes of each tree */
+    const int32_t *index, *parent;            /* node.index, node.parent (-1: root) */
+    const int32_t *site;                      /* parent_connection_coordinates: -1 none, 0 left, 1 right, 2 top */
+    const int32_t *shape;                     /* 1 box (Standard2D), 2 circle (Circular2D) */
+    const double *width, *height, *radius;    /* module_.width / height / radius */
+    const double *angle, *torque;             /* module_.angle / torque */
+    const double *ctl_amp, *ctl_phase, *ctl_freq, *ctl_offset; /* node.controller */
+} rem2d_tree_batch;
+int rem2d_compile_trees(const rem2d_tree_batch *trees, double terrain_height, int32_t lanes, const rem2d_morph *out,
+                        int32_t *n_bodies, int32_t n_threads);
+
 /* Population diversity (DataAnalysis/AdvancedDataAnalysis.py:291-313 compare_distance, :367-381
  * tree_edit_distance): out[c] = sum over t != c of the number of nodes of c whose (x, y) position does not
  * occur in t plus the number of nodes of t that no node of c sits on; positions are binary64 and compared

@@ -103,3 +103,48 @@ def test_array_population_round_trip_and_operators(built):
     before = a["mod_angle"].copy()
     sel.a["mod_angle"][:] = -1
     assert np.array_equal(a["mod_angle"], before)
+
+
+@pytest.mark.parametrize("encoding,n", [("direct", 700), ("cppn", 250), ("lsystem", 300), ("mixed", 300)])
+def test_native_tree_compiler_equals_python_compiler(built, encoding, n):
+    """rem2d_compile_trees (any encoding: the phenotype tree node by node) vs the Python compiler, word for word:
+    direct genomes (Direct_Encoding.py:18-27), network genomes (Network_Encoding.py:86-139,171-206), L-system trees
+    taken the long way round, and a mixed population."""
+    from gym_rem2d_amd.ea import Individual
+    random.seed(77)
+    kinds = {"mixed": ["direct", "lsystem", "cppn"]}.get(encoding, [encoding])
+    inds = [Individual.random(encoding=kinds[k % len(kinds)]) for k in range(n)]
+    for k, ind in enumerate(inds):
+        if k % 3 == 0:
+            for _ in range(1 + k % 3):
+                ind.mutate(0.4, 0.4, 0.3)
+    depth = 7
+    py = built.encode_population(inds, depth, workers=1)
+    nat = built.encode_trees_native(inds, depth, n_threads=3)
+    assert [b[0].lanes for b in py] == [b[0].lanes for b in nat]
+    for (mp, ip), (mn, in_) in zip(py, nat):
+        assert ip == in_
+        assert np.array_equal(mp.n_bodies, mn.n_bodies)
+        for k in mp.arrays:
+            assert np.array_equal(mp.arrays[k], mn.arrays[k]), (k, encoding)
+    assert sum(len(b[1]) for b in nat) == n
+    assert max(int(b[0].n_bodies.max()) for b in nat) >= 3
+
+
+def test_native_tree_compiler_errors(built):
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.ea import Individual
+    random.seed(3)
+    inds = [Individual.random(encoding="direct") for _ in range(20)]
+    trees = [i.genome.create(7) for i in inds]
+    arrays = built.tree_batch_arrays(trees, [i.genome.moduleList for i in inds])
+    assert arrays["node_count"].max() >= 3
+    with pytest.raises(_lib.Rem2dError, match="more bodies"):
+        built.compile_tree_arrays(arrays, 2)           # 2 lanes cannot hold the larger creatures
+    with pytest.raises(ValueError, match="more than max_nodes"):
+        built.tree_batch_arrays(trees, None, max_nodes=2)
+    bad = dict(arrays)
+    bad["node_count"] = arrays["node_count"].copy()
+    bad["node_count"][0] = 1000
+    with pytest.raises(_lib.Rem2dError, match="node_count"):
+        built.compile_tree_arrays(bad, 32)
