@@ -11,5 +11,6 @@ from .controller import Controller  # noqa: F401
 from .modules import Standard2D, Circular2D, BoxConnection, CircleConnection, get_module_list  # noqa: F401
 from .compiler import build_creature, Morphology, CreatureSpec  # noqa: F401
 from .terrain import make_terrain, TerrainProfile  # noqa: F401
+from .gymshim import make, register  # noqa: F401  (gym.make('Modular2DLocomotion-v0'), gym_rem2D/__init__.py:5-7)
 
 __version__ = "0.1.0"

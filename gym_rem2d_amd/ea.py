@@ -80,9 +80,16 @@ def make_config(**kw):
 
 
 def run_ea(config=None, population=None, evaluate_batch=None, seed=None, save_dir=None, n_generations=None,
-           log=print):
+           log=print, fitness_data=None):
     """Run the generational loop.  ``evaluate_batch(list[Individual]) -> list[float]`` defaults to one
-    batched GPU episode.  Returns (population, history) with history rows (gen, min, max, mean, seconds)."""
+    batched GPU episode.  Returns (population, history) with history rows (gen, min, max, mean, seconds).
+
+    With ``save_dir`` the run leaves the reference's files in the reference's pickle format
+    (REM2D_main.py:192-194,310-329; compat.dump_reference_pickle): ``s_`` (FitnessData: percentiles per generation),
+    ``s_pop<gen>`` every ``checkpoint_frequency`` generations and ``s_elite<gen>`` whenever the best fitness is
+    positive -- the reference can resume from them or replay the elite (REM2D_main.py:165,177-178)."""
+    from .compat import FitnessData, dump_reference_pickle
+    fitness_data = fitness_data if fitness_data is not None else FitnessData()
     config = config or make_config()
     if seed is not None:
         random.seed(seed)
@@ -123,13 +130,15 @@ def run_ea(config=None, population=None, evaluate_batch=None, seed=None, save_di
         history.append(row)
         if log:
             log("Generation %d evaluated ( %.2fs ) : Min %s, Max %s, Avg %s" % (row[0], row[4], row[1], row[2], row[3]))
+        fitness_data.addFitnessData(fits, gen)
         if save_dir is not None:
             os.makedirs(save_dir, exist_ok=True)
+            prefix = os.path.join(save_dir, "s_")            # SAVE_FILE_DIRECTORY (REM2D_main.py:194)
             if gen % ckpt == 0 or gen == n_generations - 1:
-                with open(os.path.join(save_dir, "s_pop%d" % gen), "wb") as f:
-                    pickle.dump(population, f)
+                fitness_data.save(prefix)
+                dump_reference_pickle(population, prefix + "pop%d" % gen)
             best = max(population, key=lambda ind: ind.fitness)
             if best.fitness > 0.0:
-                with open(os.path.join(save_dir, "s_elite%d" % gen), "wb") as f:
-                    pickle.dump(best, f)
+                dump_reference_pickle(best, prefix + "elite%d" % gen)
+    run_ea.last_fitness_data = fitness_data
     return population, history

@@ -282,6 +282,12 @@ class Modular2D(gymshim.Env):
         self.tree_morphology = self._batch.trees[0]
         self.robot = self._batch.robots[0]
         self.world = self._batch.worlds[0][0]
+        # the reference counts the expressed controllers in every step (Modular2DEnv.py:617-630); the tree cannot change
+        # between resets, so count once
+        self._n_ctrl = sum(1 for n in self.tree_morphology.nodes
+                           if n.controller is not None and n.expressed and n.component is not None)
+        import torch
+        self._out = torch.empty(2, dtype=torch.float32, device=self.world.device)
         return
 
     def step(self, action):
@@ -289,12 +295,12 @@ class Modular2D(gymshim.Env):
             self.wod.update()
         if self.tree_morphology is None:
             raise Exception("no tree_morphology")
-        n_ctrl = sum(1 for n in self.tree_morphology.nodes
-                     if n.controller is not None and n.expressed and n.component is not None)
-        assert n_ctrl - 1 == len(self.robot.joints)
-        reward, done = self._batch.step(1)
-        r = float(reward[0])
-        d = bool(done[0])
+        assert self._n_ctrl - 1 == len(self.robot.joints)
+        self.world.step(1)                      # one creature: straight to the C ABI, no bucket / group bookkeeping
+        self._out[0] = self.world.view("reward")[0]
+        self._out[1] = self.world.view("done")[0]
+        r, d = self._out.tolist()               # one device -> host copy per step (the caller wants python scalars)
+        d = d != 0.0
         return 0, (r if not d else -100), (True if d else 0), 0
 
     def render(self, mode='human'):

@@ -35,9 +35,18 @@ def test_generation_loop_with_stub_evaluator(tmp_path):
     assert calls == [24] * 7 and len(pop) == 24 and len(hist) == 6
     assert hist[-1][3] >= hist[0][3]               # mean fitness does not collapse
     assert (tmp_path / "s_pop0").exists() and (tmp_path / "s_pop5").exists() and (tmp_path / "s_elite5").exists()
-    import pickle
-    best = pickle.load(open(tmp_path / "s_elite5", "rb"))
+    # the files are in the reference's pickle format (class paths of REM2D_main / Encodings / gym_rem2D ...)
+    from gym_rem2d_amd.compat import FitnessData, load_reference_pickle
+    best = load_reference_pickle(str(tmp_path / "s_elite5"))
     assert best.fitness == max(p.fitness for p in pop)
+    saved = load_reference_pickle(str(tmp_path / "s_pop5"))
+    assert [i.fitness for i in saved] == [i.fitness for i in pop]
+    fd = load_reference_pickle(str(tmp_path / "s_"))
+    assert isinstance(fd, FitnessData) and len(fd.avg) == 6 and fd.p_100[-1] == hist[-1][2] and fd.p_0[-1] == hist[-1][1]
+    import pickletools
+    names = {a for op, a, _ in pickletools.genops(open(tmp_path / "s_pop5", "rb").read()) if op.name == "GLOBAL"}
+    assert "REM2D_main Individual" in names and "Encodings.direct_encoding DirectEncoding" in names
+    assert not any(n.startswith("gym_rem2d_amd") for n in names)
 
 
 def test_individual_random_matches_module_defaults():

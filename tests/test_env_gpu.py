@@ -224,3 +224,27 @@ def test_solver_overflow_is_not_silent(need_gpu):
     assert fit.shape == (4,) and bool(check_errors(env, "ignore")[2]) and int(check_errors(env, "ignore").sum()) == 1
     env.close()
     torch.cuda.synchronize()
+
+
+def test_state_dump_for_external_viewers(need_gpu, tmp_path):
+    """statedump.record_episode: JSON lines (header with terrain + morphology, then frames with poses / wall of death /
+    reward) and the draw list Modular2D.render would paint (Modular2DEnv.py:655-738)."""
+    import json
+    from gym_rem2d_amd import synthetic, statedump
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(6))
+    env = BatchedModular2D()
+    env.reset_specs(specs)
+    path = statedump.record_episode(env, str(tmp_path / "run.jsonl"), steps=40, creatures=(0, 4), every=10)
+    lines = open(path).read().splitlines()
+    head, frames = json.loads(lines[0]), [json.loads(l) for l in lines[1:]]
+    assert head["kind"] == "rem2d_state_dump" and len(head["terrain"]["x"]) == 200 and len(frames) == 5
+    assert [c["index"] for c in head["creatures"]] == [0, 4]
+    assert [len(c["bodies"]) for c in head["creatures"]] == [specs[0].n_bodies, specs[4].n_bodies]
+    assert frames[0]["step"] == 0 and frames[-1]["step"] == 40
+    assert frames[-1]["creatures"][0]["wall_of_death"] == pytest.approx(40 * 0.04)
+    y0, y1 = frames[0]["creatures"][0]["pose"][0][1], frames[-1]["creatures"][0]["pose"][0][1]
+    assert y1 < y0                                        # it fell from the spawn height
+    prims = statedump.frame_to_draw_list(head, frames[-1])
+    assert len(prims) == 2 and sum(p[0] in ("polygon", "circle") for p in prims[0]) == specs[0].n_bodies
+    env.close()
