@@ -567,7 +567,7 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
     }
 }
 template <int K>
-DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
+DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, ToiShared &ts) {
     const unsigned idx = block * WAVE + threadIdx.x;
     if (block * WAVE >= (unsigned)S.toiWork[0]) return;
     if (idx >= (unsigned)S.toiWork[0]) return;
@@ -579,7 +579,7 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     B.px = LF(L_PX); B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
     B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
     B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
-                       SW(wb, 2), B);
+                       SW(wb, 2), B, ts, (int)threadIdx.x);
     LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
     LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
     if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
@@ -593,7 +593,8 @@ __global__ __launch_bounds__(WAVE) void rem2d_toi_scan_kernel(State S, Terrain T
 }
 template <int K>
 __global__ __launch_bounds__(WAVE, 2) void rem2d_toi_heavy_kernel(State S, Terrain T, StepArgs A) {
-    toi_heavy_body<K>(S, T, A, blockIdx.x);
+    __shared__ ToiShared ts;
+    toi_heavy_body<K>(S, T, A, blockIdx.x, ts);
 }
 __global__ __launch_bounds__(WAVE) void rem2d_toi_scan_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
@@ -601,9 +602,10 @@ __global__ __launch_bounds__(WAVE) void rem2d_toi_scan_multi_kernel(Batch B, Ste
     BATCH_DISPATCH(toi_scan_body)
 }
 __global__ __launch_bounds__(WAVE, 2) void rem2d_toi_heavy_multi_kernel(Batch B, StepArgs A) {
+    __shared__ ToiShared ts;
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
-    BATCH_DISPATCH(toi_heavy_body)
+    BATCH_DISPATCH(toi_heavy_body, ts)
 }
 
 // =====================================================================================

@@ -110,14 +110,22 @@ template <int K> DEV int group_or(int v) {
     for (int o = 1; o < K; o <<= 1) v |= __shfl_xor(v, o);
     return v;
 }
-// Mailbox hand-off between lanes of ONE wave (workgroup == wavefront): LDS operations of a wave
-// execute in issue order, so all that is needed is that the compiler neither reorders the LDS
-// accesses across this point nor forwards stale values: release + acquire at workgroup scope
-// (lowers to s_waitcnt lgkmcnt(0)); no s_barrier is required.
+// Mailbox hand-off between lanes of ONE wave (workgroup == wavefront).  The LDS operations of a wave execute in issue
+// order, so a ds_read issued after a ds_write of another lane of the same wave sees the written value without any
+// wait in between; all that is needed is that the compiler neither reorders the LDS accesses across this point nor
+// forwards stale values: release + acquire at WAVEFRONT scope (no s_waitcnt is emitted for it -- the only waits left
+// are the ones in front of the first use of loaded data; at workgroup scope every hand-off drained lgkmcnt, ~100
+// cycles of exposed latency per slot of the solver loops).  REM2D_LDS_SYNC_WORKGROUP restores the conservative form.
 DEV void lds_sync() {
+#ifdef REM2D_LDS_SYNC_WORKGROUP
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 DEV int wave_max(int v) {
 #pragma unroll

@@ -24,6 +24,60 @@ struct PosShared {
     float snap[POS_RING][3][WAVE];
     int firstR[WAVE], lastR[WAVE];
 };
+// manifold geometry as the position solver reads it (b2PositionSolverManifold): type | count << 8, local normal,
+// local point, two manifold points
+#define POS_KR 2
+struct PosManifold { int tc; V2 ln, lp, p0, p1; };
+DEV void pos_manifold_load(const State &S, unsigned gl, int t, PosManifold &m) {
+    const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
+    m.tc = __float_as_int(SW(sb, 0));
+    m.ln = mk(SW(sb, 1), SW(sb, 2)); m.lp = mk(SW(sb, 3), SW(sb, 4));
+    m.p0 = mk(SW(sb, 5), SW(sb, 6)); m.p1 = mk(SW(sb, 7), SW(sb, 8));
+}
+// b2ContactSolver::SolvePositionConstraints for one manifold between the static ground (A) and this body (B)
+DEV void pos_solve_manifold(const PosManifold &m, float mB, float iB, float radiusB, float &cx, float &cy, float &ca,
+                            float &minSeparation) {
+    const int mtype = m.tc & 0xff, mcount = m.tc >> 8;
+    const float radiusA = B2_POLYGON_RADIUS;
+    for (int j = 0; j < mcount; ++j) {
+        const V2 pj = j == 0 ? m.p0 : m.p1;
+        V2 cB = mk(cx, cy);
+        V2 normal, point;
+        float separation;
+        Rot qB = rot_set(ca);
+        if (mtype == MF_CIRCLES) {
+            V2 pointA = m.lp;
+            V2 pointB = xmul(qB, cB, m.p0);
+            normal = vsub(pointB, pointA);
+            vnormalize(normal);
+            point = vscale(0.5f, vadd(pointA, pointB));
+            separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
+        } else if (mtype == MF_FACE_A) {
+            normal = m.ln;
+            V2 planePoint = m.lp;
+            V2 clipPoint = xmul(qB, cB, pj);
+            separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+            point = clipPoint;
+        } else {
+            normal = rmul(qB, m.ln);
+            V2 planePoint = xmul(qB, cB, m.lp);
+            V2 clipPoint = pj;
+            separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
+            point = clipPoint;
+            normal = vneg(normal);
+        }
+        V2 rBp = vsub(point, cB);
+        minSeparation = fmin32(minSeparation, separation);
+        float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
+        float rnB = vcross(rBp, normal);
+        float Kn = mB + iB * rnB * rnB;
+        float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+        V2 Pc = vscale(impulse, normal);
+        cx = cx + mB * Pc.x;
+        cy = cy + mB * Pc.y;
+        ca += iB * vcross(rBp, Pc);
+    }
+}
 template <int K> DEV int group_max(int v) {
 #pragma unroll
     for (int o = 1; o < K; o <<= 1) {
@@ -37,9 +91,14 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                                    int jround, int period, int nTouch, float mA, float iA, float mB, float iB, float radiusB,
                                    int limitState, float motorMass, int posIters, float &px, float &py, float &ang,
                                    bool &envSolved, int &itersUsed) {
-    const unsigned Lp = S.Lp;
     const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
     const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
+    PosManifold pm[POS_KR];
+#pragma unroll
+    for (int t = 0; t < POS_KR; ++t) {
+        pm[t].tc = 0; pm[t].ln = pm[t].lp = pm[t].p0 = pm[t].p1 = mk(0.0f, 0.0f);
+        if (active && t < nTouch) pos_manifold_load(S, gl, t, pm[t]);
+    }
     // first / last joint round of every body (its own joint and those of its children)
     sh.firstR[lane] = 0x7fffffff;
     sh.lastR[lane] = -1;
@@ -69,50 +128,13 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         if (tick == nextC) {
             float cx = sh.mbox[0][lane], cy = sh.mbox[1][lane], ca = sh.mbox[2][lane];
             float minSeparation = 0.0f;
-            for (int t = 0; t < nTouch; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
-                int mtype = tc & 0xff, mcount = tc >> 8;
-                V2 lnrm = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
-                const float radiusA = B2_POLYGON_RADIUS;
-                for (int j = 0; j < mcount; ++j) {
-                    V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
-                    V2 cB = mk(cx, cy);
-                    V2 normal, point;
-                    float separation;
-                    Rot qB = rot_set(ca);
-                    if (mtype == MF_CIRCLES) {
-                        V2 pointA = lp;
-                        V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
-                        normal = vsub(pointB, pointA);
-                        vnormalize(normal);
-                        point = vscale(0.5f, vadd(pointA, pointB));
-                        separation = vdot(vsub(pointB, pointA), normal) - radiusA - radiusB;
-                    } else if (mtype == MF_FACE_A) {
-                        normal = lnrm;
-                        V2 planePoint = lp;
-                        V2 clipPoint = xmul(qB, cB, pj);
-                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                    } else {
-                        normal = rmul(qB, lnrm);
-                        V2 planePoint = xmul(qB, cB, lp);
-                        V2 clipPoint = pj;
-                        separation = vdot(vsub(clipPoint, planePoint), normal) - radiusA - radiusB;
-                        point = clipPoint;
-                        normal = vneg(normal);
-                    }
-                    V2 rBp = vsub(point, cB);
-                    minSeparation = fmin32(minSeparation, separation);
-                    float C = fclamp(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), -B2_MAX_LINEAR_CORRECTION, 0.0f);
-                    float rnB = vcross(rBp, normal);
-                    float Kn = mB + iB * rnB * rnB;
-                    float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                    V2 Pc = vscale(impulse, normal);
-                    cx = cx + mB * Pc.x;
-                    cy = cy + mB * Pc.y;
-                    ca += iB * vcross(rBp, Pc);
-                }
+#pragma unroll
+            for (int t = 0; t < POS_KR; ++t) // the first manifolds of the body: geometry preloaded into registers
+                if (t < nTouch) pos_solve_manifold(pm[t], mB, iB, radiusB, cx, cy, ca, minSeparation);
+            for (int t = POS_KR; t < nTouch; ++t) { // further ones (rare): re-read from scratch in every iteration
+                PosManifold m;
+                pos_manifold_load(S, gl, t, m);
+                pos_solve_manifold(m, mB, iB, radiusB, cx, cy, ca, minSeparation);
             }
             if (!(minSeparation >= -3.0f * B2_LINEAR_SLOP)) failBits |= 1ull << (itC & 63);
             sh.mbox[0][lane] = cx; sh.mbox[1][lane] = cy; sh.mbox[2][lane] = ca;

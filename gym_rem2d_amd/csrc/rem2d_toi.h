@@ -477,8 +477,20 @@ DEV bool toi_far_apart(const Proxy &pA, const Proxy &pB, const Sweep &sw, int sh
 struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, events; };
 
 // b2World::SolveTOI restricted to this lane's body (see the section comment above).
+// The TOI island's manifolds (<= KT per body) live in LDS while the sub-step is solved: the 20 TOI position
+// iterations and the constraint set-up read them again and again, and a round trip to the scratch arena in HBM/L2
+// per word was most of this kernel's latency chain.  [word][lane]: conflict-free for a wavefront.
+struct ToiShared { float m[KT * SCR_WORDS][WAVE]; };
+DEV void island_store(ToiShared &ts, int lane, int t, const Manifold &m) {
+    float (*w)[WAVE] = ts.m + t * SCR_WORDS;
+    w[0][lane] = __int_as_float(m.type | (m.count << 8));
+    w[1][lane] = m.ln.x; w[2][lane] = m.ln.y; w[3][lane] = m.lp.x; w[4][lane] = m.lp.y;
+    w[5][lane] = m.p0.x; w[6][lane] = m.p0.y; w[7][lane] = m.p1.x; w[8][lane] = m.p1.y;
+}
+#define IW(t, k) (ts.m[(t) * SCR_WORDS + (k)][lane])
 DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int shape, float hx, float hy, float mB, float iB,
-                                                float h, int velIters, float c0x, float c0y, float a0, LaneBody B) {
+                                                float h, int velIters, float c0x, float c0y, float a0, LaneBody B,
+                                                ToiShared &ts, int lane) {
     const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
     const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
     const float friction = T.friction;
@@ -560,7 +572,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
         // ---- TOI island: this body, the TOI contact, then its other touching contacts (list order) ----
         int nIsl = 0;
         unsigned islPack = 0u;
-        manifold_store(S, gl, 0, m);
+        island_store(ts, lane, 0, m);
         islPack |= (unsigned)minSlot;
         nIsl = 1;
         CI(C_INFO, om) = CI(C_INFO, om) | CI_ISLAND;
@@ -571,7 +583,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             contact_update_slot(S, T, o, shape, hx, hy, p, q, mo, sleepResetAlways, B.sleepT);
             if (mo.count == 0) continue;
             if (nIsl >= KT) { B.err |= REM2D_ERR_SOLVER_OVERFLOW; continue; }
-            manifold_store(S, gl, nIsl, mo);
+            island_store(ts, lane, nIsl, mo);
             islPack |= (unsigned)s << (5 * nIsl);
             ++nIsl;
         }
@@ -580,20 +592,19 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
         for (int it = 0; it < 20; ++it) { // SolveTOIPositionConstraints: only this body moves
             float minSeparation = 0.0f;
             for (int t = 0; t < nIsl; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
+                int tc = __float_as_int(IW(t, 0));
                 int mtype = tc & 0xff, mcount = tc >> 8;
-                V2 ln = mk(SW(sb, 1), SW(sb, 2)), lp = mk(SW(sb, 3), SW(sb, 4));
+                V2 ln = mk(IW(t, 1), IW(t, 2)), lp = mk(IW(t, 3), IW(t, 4));
                 const float radiusA = B2_POLYGON_RADIUS;
                 for (int j = 0; j < mcount; ++j) {
-                    V2 pj = mk(SW(sb, 5 + 2 * j), SW(sb, 6 + 2 * j));
+                    V2 pj = mk(IW(t, 5 + 2 * j), IW(t, 6 + 2 * j));
                     V2 cB = mk(cx, cy);
                     V2 normal, point;
                     float separation;
                     Rot qB = rot_set(ca);
                     if (mtype == MF_CIRCLES) {
                         V2 pointA = lp;
-                        V2 pointB = xmul(qB, cB, mk(SW(sb, 5), SW(sb, 6)));
+                        V2 pointB = xmul(qB, cB, mk(IW(t, 5), IW(t, 6)));
                         normal = vsub(pointB, pointA);
                         vnormalize(normal);
                         point = vscale(0.5f, vadd(pointA, pointB));
@@ -637,19 +648,17 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             for (int t = 0; t < KR; ++t) {
                 tcc[t].count = 0;
                 if (t < nIsl) {
-                    const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                    int tc = __float_as_int(SW(sb, 0));
-                    contact_setup(tcc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
-                                  mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f,
+                    int tc = __float_as_int(IW(t, 0));
+                    contact_setup(tcc[t], tc & 0xff, tc >> 8, mk(IW(t, 1), IW(t, 2)), mk(IW(t, 3), IW(t, 4)),
+                                  mk(IW(t, 5), IW(t, 6)), mk(IW(t, 7), IW(t, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f,
                                   0.0f, 0.0f);
                 }
             }
             for (int t = KR; t < nIsl; ++t) {
-                const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
-                int tc = __float_as_int(SW(sb, 0));
+                int tc = __float_as_int(IW(t, 0));
                 ContactC c;
-                contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)), mk(SW(sb, 5), SW(sb, 6)),
-                              mk(SW(sb, 7), SW(sb, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
+                contact_setup(c, tc & 0xff, tc >> 8, mk(IW(t, 1), IW(t, 2)), mk(IW(t, 3), IW(t, 4)), mk(IW(t, 5), IW(t, 6)),
+                              mk(IW(t, 7), IW(t, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
                 cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
             }
             for (int it = 0; it < velIters; ++it) {
