@@ -22,6 +22,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (every binary32 operation rounded
 // separately, like an x86-64 Box2D build; this is what makes bit-exact parity possible).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cfloat>
 #include <cmath>
@@ -312,10 +313,13 @@ extern "C" int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, in
 }
 
 static void drain_timing(rem2d_world *w) {
+    // the device is drained once; after that every recorded pair is complete.  (No hipEventSynchronize per event: the
+    // start / stop events of hipExtLaunchKernelGGL are not stream records, and waiting on one can block for ever.)
+    if (w->evUsed > 0 || w->evUsedStep > 0) (void)hipDeviceSynchronize();
     for (int i = 0; i < w->evUsed; ++i) {
         auto &p = w->evPool[i];
         float ms = 0.0f;
-        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             w->accumMs += ms;
             w->launches += 1;
         }
@@ -324,12 +328,13 @@ static void drain_timing(rem2d_world *w) {
     for (int i = 0; i < w->evUsedStep; ++i) {
         auto &p = w->evPoolStep[i];
         float ms = 0.0f;
-        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             w->accumMsStep += ms;
             w->launchesStep += 1;
         }
     }
     w->evUsedStep = 0;
+    (void)hipGetLastError(); // an event pair that was never reached leaves hipErrorInvalidHandle / NotReady behind
 }
 static void free_timing(rem2d_world *w) {
     for (auto *pool : {&w->evPool, &w->evPoolStep}) {
@@ -548,14 +553,18 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                                hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
         hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
-        const bool timed = timing_begin(w0, st);
+        // dominant kernel: its own begin / end timestamps (hipExtLaunchKernelGGL's start / stop events bracket exactly
+        // the kernel, which is what rocprofv3 --kernel-trace reports; events recorded on the stream around the launch
+        // also count the dispatch gaps, 50-100 us when three step groups share the command processor)
+        const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
+        hipEvent_t e0 = timed ? w0->evPool[w0->evUsed].first : nullptr, e1 = timed ? w0->evPool[w0->evUsed].second : nullptr;
         switch (tile_shape_id()) {
-        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, VB, V); break;
-        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, VB, V); break;
-        case 2: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 5>), dim3(tiles), block, 0, st, VB, V); break;
-        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, VB, V); break;
+        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
+        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
+        case 2: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 5>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
+        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         }
-        if (timed) timing_end(w0, st);
+        if (timed) w0->evUsed += 1;
         hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
         if (continuous) {
             hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
@@ -737,6 +746,16 @@ extern "C" int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int6
     w->launches = 0;
     return REM2D_OK;
 }
+#ifdef REM2D_TOI_STAMPS
+// diagnostic builds only: the TOI kernel's cycle counters (toiWork[0..16)), then zeroed
+extern "C" int rem2d_world_debug_words(rem2d_world *w, int32_t *out16) {
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, w->S.toiWork, 16 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(w->S.toiWork + 1, 0, 15 * sizeof(int)));
+    return REM2D_OK;
+}
+#endif
 extern "C" int rem2d_world_step_time_ms(rem2d_world *w, double *total_ms, int64_t *steps) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
     HIP_TRY(hipSetDevice(w->cfg.device));

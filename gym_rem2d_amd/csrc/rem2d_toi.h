@@ -350,13 +350,17 @@ DEV void contact_update_slot(const State &S, const Terrain &T, unsigned o, int s
         if (oldCount > 0 && ok0 == m.k1) { n1 = on0; t1 = ot0; }
         else if (oldCount > 1 && ok1 == m.k1) { n1 = on1; t1 = ot1; }
     }
-    CI(C_INFO, o) = (info & CI_KEEP_MASK) | CI_ENABLED | m.count | (m.type << 8);
-    CU(C_KEY0, o) = m.k0;
-    CU(C_KEY1, o) = m.k1;
-    CF(C_N0, o) = n0;
-    CF(C_N1, o) = n1;
-    CF(C_T0, o) = t0;
-    CF(C_T1, o) = t1;
+    // Most pairs of a body are broadphase overlaps that do not touch: nothing about them changes from step to step.
+    // Store only words whose BITS change (so the arena holds exactly what an unconditional store would leave): the
+    // pair lists were a third of the step's HBM write traffic.
+    const int newInfo = (info & CI_KEEP_MASK) | CI_ENABLED | m.count | (m.type << 8);
+    if (newInfo != info) CI(C_INFO, o) = newInfo;
+    if (m.k0 != ok0) CU(C_KEY0, o) = m.k0;
+    if (m.k1 != ok1) CU(C_KEY1, o) = m.k1;
+    if (__float_as_uint(n0) != __float_as_uint(on0)) CF(C_N0, o) = n0;
+    if (__float_as_uint(n1) != __float_as_uint(on1)) CF(C_N1, o) = n1;
+    if (__float_as_uint(t0) != __float_as_uint(ot0)) CF(C_T0, o) = t0;
+    if (__float_as_uint(t1) != __float_as_uint(ot1)) CF(C_T1, o) = t1;
 }
 DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
@@ -505,6 +509,12 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
     }
     const Proxy pB = proxy_body(shape, hx, hy);
     const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f; // circumradius of the core shape
+#ifdef REM2D_TOI_STAMPS
+    unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk, cyc[5] = {0, 0, 0, 0, 0};
+#define TOI_STAMP(i) do { tk = __builtin_amdgcn_s_memtime(); cyc[i] += tk - tk0; tk0 = tk; } while (0)
+#else
+#define TOI_STAMP(i) do {} while (0)
+#endif
     for (;;) {
         int minSlot = -1;
         float minAlpha = 1.0f;
@@ -537,6 +547,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             }
             if (alpha < minAlpha) { minSlot = s; minAlpha = alpha; }
         }
+        TOI_STAMP(0); // alpha pass: b2TimeOfImpact of every pair whose TOI is not cached
         if (minSlot < 0 || 1.0f - 10.0f * B2_EPSILON < minAlpha) break;
         // ---- advance the body to the TOI (b2Body::Advance) ----
         const Sweep backup = sw;
@@ -587,6 +598,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             islPack |= (unsigned)s << (5 * nIsl);
             ++nIsl;
         }
+        TOI_STAMP(1); // contact updates (TOI contact + the body's other pairs)
         // ---- b2Island::SolveTOI ----
         float cx = sw.c.x, cy = sw.c.y, ca = sw.a;
         for (int it = 0; it < 20; ++it) { // SolveTOIPositionConstraints: only this body moves
@@ -636,6 +648,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             }
             if (minSeparation >= -1.5f * B2_LINEAR_SLOP) break;
         }
+        TOI_STAMP(2); // TOI position iterations
         // leap of faith to the new safe state
         sw.c0 = mk(cx, cy);
         sw.a0 = ca;
@@ -692,6 +705,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 if (!changed) break;
             }
         }
+        TOI_STAMP(3); // constraint set-up + velocity iterations
         // integrate the remaining (1 - minAlpha) * dt; TOI impulses are not stored
         {
             float hs = (1.0f - minAlpha) * h;
@@ -740,6 +754,20 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 }
             }
         }
+#ifdef REM2D_TOI_STAMPS
+        TOI_STAMP(4); // integrate, flags, SynchronizeFixtures, FindNewContacts
+    }
+    {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 5; ++i) { atomicAdd(&S.toiWork[2 + i], (int)(cyc[i] >> 6)); tot += cyc[i]; }
+        atomicMax(&S.toiWork[8], (int)(tot >> 6));
+        atomicAdd(&S.toiWork[9], B.events);
+        atomicMax(&S.toiWork[10], B.events);
+        atomicAdd(&S.toiWork[11], 1);
+#else
+    }
+    {
+#endif
     }
     B.px = sw.c.x; B.py = sw.c.y; B.ang = sw.a;
     return B;

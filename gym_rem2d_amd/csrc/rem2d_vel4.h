@@ -35,7 +35,12 @@
 #define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
 #define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
-struct Vel4Args { int velIters; float dt; int dbg; /* REM2D_V4_DBG: 1 skip contact sub-slots, 2 skip joint slots (timing probes only) */ };
+struct Vel4Args { int velIters; float dt; int dbg; /* diagnostic builds (-DREM2D_V4_PROBES) only: 1 skip contact sub-slots, 2 skip joint slots, 8 s_memtime split */ };
+#ifdef REM2D_V4_PROBES
+#define V4_DBG(A) ((A).dbg)
+#else
+#define V4_DBG(A) 0
+#endif
 
 struct __attribute__((aligned(16))) V4Vel { float x, y, w, invI; };
 template <int SETS, int PASSES> struct Vel4Shared {
@@ -353,7 +358,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const int nRounds = wave_max(maxRound) + 1;
     maxT = wave_max(maxT);
 #pragma unroll
-    for (int s = 0; s < V4_PHASES; ++s) subMax[s] = (A.dbg & 1) ? 0 : wave_max(subMax[s]);
+    for (int s = 0; s < V4_PHASES; ++s) subMax[s] = (V4_DBG(A) & 1) ? 0 : wave_max(subMax[s]);
     lds_sync();
 
     // ---------------- joint role: one joint per phase and lane ----------------
@@ -432,8 +437,8 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     // ---------------- velocity iterations: ticks in groups of one period, phase = position in the group ----------------
     {
         const int span = iters * P; // joint k fires at ticks jround + i P, i < iters, i.e. while tick - jround < span
-        const bool joints = !(A.dbg & 2);
-        const bool stamp = (A.dbg & 8) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py)
+        const bool joints = !(V4_DBG(A) & 2);
+        const bool stamp = (V4_DBG(A) & 8) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py)
         unsigned long long tJ = 0, tC = 0, t0 = 0, t1 = 0, nSub = 0;
         const unsigned long long tStart = stamp ? __builtin_amdgcn_s_memtime() : 0;
         for (int base = 0; base < nTicks; base += P) {

@@ -6,6 +6,9 @@
                                                             HBM bytes per launch per kernel from the separate
                                                             `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
   collect_profiles.py sq     <dir> <out.json> <label>       SQ counters per launch per kernel (lanes per VALU instruction)
+  collect_profiles.py trace  <dir> <out.json> <n> <label>   per-kernel mean duration over the LAST n dispatches of each
+                                                            kernel in kernel_trace.csv (= bench.py's timed region; the
+                                                            --stats table averages the settle phase in as well)
 
 Per-launch means are taken over the last `--tail` launches of each kernel (default 30: the timed region, settled
 state).  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB.  On gfx950 FETCH_SIZE counts a 128-byte fabric read
@@ -85,6 +88,23 @@ def main():
                    "note": "means over the last %d launches of each kernel; active_lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / "
                            "SQ_INSTS_VALU (64 = every lane active)" % tail,
                    "kernels": c}, open(args[2], "w"), indent=1)
+    elif mode == "trace":
+        n = int(args[3])
+        per = defaultdict(list)
+        with open(find(args[1], "*kernel_trace.csv")) as f:
+            for row in csv.DictReader(f):
+                per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        out = {}
+        for k, v in per.items():
+            v.sort()
+            d = [e - b for b, e in v]
+            out[k] = {"dispatches": len(d), "avg_us_all": sum(d) / len(d) / 1e3,
+                      "avg_us_last_%d" % n: sum(d[-n:]) / len(d[-n:]) / 1e3}
+        json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- " + args[4],
+                   "note": "mean kernel duration from kernel_trace.csv; the last %d dispatches of the step kernels are bench.py's "
+                           "timed region (steps x step groups) -- the number its HIP-event figure roofline.avg_launch_ms must "
+                           "agree with; avg_us_all (what --stats prints) also averages the cheaper settle phase" % n,
+                   "kernels": out}, open(args[2], "w"), indent=1)
     else:
         raise SystemExit(__doc__)
 
