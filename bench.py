@@ -381,9 +381,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload_desc, "envs_per_gpu": n_envs,
-                       "pipeline": {3: "tile (pre / vel4 / post / toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
+                       "pipeline": {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
                                     1: "split (4-wave velocity kernel)", 2: "split (vel3)"}[pipeline],
-                       "kernel_launches_per_env_step_per_group": (5 if not args.discrete else 3) if pipeline == 3 else None,
+                       "kernel_launches_per_env_step_per_group": (4 if not args.discrete else 3) if pipeline == 3 else None,
                        "steps_per_abi_call": spl,
                        "settle_steps": args.settle,
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,

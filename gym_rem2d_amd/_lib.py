@@ -62,6 +62,17 @@ class TreeBatch(C.Structure):
         "ctl_phase", "ctl_freq", "ctl_offset")]
 
 
+class NetworkGenomes(C.Structure):
+    """rem2d_network_genomes (include/rem2d.h)."""
+    _fields_ = ([("n", C.c_int32), ("n_types", C.c_int32), ("n_hidden", C.c_int32), ("max_modules", C.c_int32)]
+                + [(k, C.c_void_p) for k in ("w1", "a1", "w2", "mod_shape", "mod_width", "mod_height", "mod_radius",
+                                             "mod_angle", "mod_torque", "ctl_amp", "ctl_phase", "ctl_freq", "ctl_offset")]
+                + [(k, C.c_double) for k in ("box_min_width", "box_max_width", "box_min_height", "box_max_height",
+                                             "box_min_angle", "box_max_angle", "circle_min_radius", "circle_max_radius",
+                                             "circle_min_angle", "circle_max_angle", "ctl_max_amp", "ctl_max_phase",
+                                             "ctl_max_offset", "ctl_max_freq")])
+
+
 class Rem2dError(RuntimeError):
     pass
 
@@ -121,6 +132,8 @@ def lib():
     L.rem2d_compile_lsystem.argtypes = [C.POINTER(LsystemGenomes), C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                         C.POINTER(Morph), C.c_void_p, C.c_int32]
     L.rem2d_compile_trees.argtypes = [C.POINTER(TreeBatch), C.c_double, C.c_int32, C.POINTER(Morph), C.c_void_p, C.c_int32]
+    L.rem2d_compile_network.argtypes = [C.POINTER(NetworkGenomes), C.c_int32, C.c_double, C.c_int32, C.POINTER(Morph),
+                                        C.c_void_p, C.c_int32]
     L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]

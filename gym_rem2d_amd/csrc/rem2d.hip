@@ -542,7 +542,7 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
-    A.defer = continuous ? 1 : 0;
+    A.defer = continuous ? 2 : 0; // 2: post runs the TOI scan itself (the fused kernel's path keeps 1 = separate scan kernel)
     Vel4Args V;
     V.velIters = vel_iters;
     V.dt = dt;
@@ -566,10 +566,7 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         }
         if (timed) w0->evUsed += 1;
         hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
-        if (continuous) {
-            hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
-            hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
-        }
+        if (continuous) hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
         if (timedStep) {
             (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
             w0->evUsedStep += 1;

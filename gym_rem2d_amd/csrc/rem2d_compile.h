@@ -405,4 +405,204 @@ extern "C" int rem2d_compile_trees(const rem2d_tree_batch *B, double terrain_hei
     return REM2D_OK;
 }
 
+// ---- Network encoding (Network_Encoding.py:42-222): a function queried per connection site grows the tree ----
+// Restates NNEncoding.create / _grow / _query / _emit (gym_rem2d_amd/encodings/network.py, the mirror of the reference's
+// update / iterate / create / recursiveNodeGen) and Standard2D / Circular2D.setMorph + limitWH, Controller.setControl +
+// minMax, in binary64 with the same libm calls in the same order as the Python floats.  The genome of this build is the
+// synthetic feed-forward CPPN (neat-python is absent): per hidden node one of four activation functions.
+namespace rem2d_host {
+
+static inline double pymax(double a, double b) { return b > a ? b : a; } // python's max(a, b): first maximal element
+static inline double pymin(double a, double b) { return b < a ? b : a; }
+
+struct NetSym { int index, parent, ref, site; bool handled; int nChild; int child[3]; int node; };
+
+struct NetExpander {
+    const rem2d_network_genomes &G;
+    const int e, T, H, maxDepth, maxModules;
+    NetSym pool[4 * MAXN];
+    int nPool;
+    bool overflow;
+    // per-symbol module / controller parameters (the child's own copies)
+    int shape[4 * MAXN];
+    double width[4 * MAXN], height[4 * MAXN], radius[4 * MAXN], angle[4 * MAXN], torque[4 * MAXN];
+    double amp[4 * MAXN], phase[4 * MAXN], freq[4 * MAXN], offset[4 * MAXN];
+    NetExpander(const rem2d_network_genomes &g, int ee, int depth)
+        : G(g), e(ee), T(g.n_types), H(g.n_hidden), maxDepth(depth), maxModules(g.max_modules), nPool(0), overflow(false) {}
+    double proto(const double *a, int t) const { return a[(size_t)e * T + t]; }
+    void activate(const double x[3], double out[10]) const {
+        double h[64];
+        const double *w1 = G.w1 + (size_t)e * H * 4;
+        const int32_t *a1 = G.a1 + (size_t)e * H;
+        const double *w2 = G.w2 + (size_t)e * 10 * (H + 1);
+        for (int k = 0; k < H; ++k) {
+            double s = 0.0; // python sum(): 0 + w0 x0 + w1 x1 + w2 x2 + w3 * 1.0, left to right
+            s = s + w1[k * 4 + 0] * x[0];
+            s = s + w1[k * 4 + 1] * x[1];
+            s = s + w1[k * 4 + 2] * x[2];
+            s = s + w1[k * 4 + 3] * 1.0;
+            switch (a1[k]) {
+            case 0: h[k] = tanh(s); break;
+            case 1: h[k] = sin(s); break;
+            case 2: h[k] = exp(-s * s) * 2 - 1; break;
+            default: h[k] = pymax(-1.0, pymin(1.0, s)); break;
+            }
+        }
+        for (int o = 0; o < 10; ++o) {
+            double s = 0.0;
+            for (int k = 0; k < H; ++k) s = s + w2[o * (H + 1) + k] * h[k];
+            s = s + w2[o * (H + 1) + H] * 1.0;
+            out[o] = tanh(s);
+        }
+    }
+    int query(int index, int s, int depth) { // NNEncoding._query: one network query per free connection site
+        if (depth > maxDepth || index > maxModules) return index;
+        const NetSym parent = pool[s];
+        if (shape[s] != 1) return index; // circles offer no connection sites (circular_module.py:31-53)
+        static const double siteValue[3] = {-1.0, 1.0, 0.0}; // BoxConnection left, right, top: con.value[0]
+        for (int c = 0; c < 3; ++c) {
+            double x[3], out[10];
+            x[0] = 1.0 - (2.0 * ((double)depth / (double)maxDepth));
+            x[1] = 1.0 - (2.0 * ((double)(parent.ref + 1) / (double)T));
+            x[2] = siteValue[c];
+            activate(x, out);
+            if (out[0] > 0.5) {
+                out[1] = pymax(-1., pymin(1., out[1]));
+                int ref = (int)(((out[1] * 0.5) + 0.5) * (double)(T - 1)); // int(): towards zero
+                ref = ref < 0 ? 0 : (ref > T - 1 ? T - 1 : ref);
+                if (nPool >= 4 * MAXN) { overflow = true; return index; }
+                const int k = nPool++;
+                NetSym &f = pool[k];
+                f.index = index; f.parent = parent.index; f.ref = ref; f.site = c; f.handled = false; f.nChild = 0; f.node = -1;
+                // child.module = deepcopy(moduleList[ref]); child.module.setMorph(out[2], out[3], out[4])
+                shape[k] = G.mod_shape[(size_t)e * T + ref];
+                torque[k] = proto(G.mod_torque, ref);
+                width[k] = proto(G.mod_width, ref); height[k] = proto(G.mod_height, ref); radius[k] = proto(G.mod_radius, ref);
+                if (shape[k] == 1) {
+                    width[k] = (out[2] * 0.5 * (G.box_max_width - G.box_min_width)) + 0.5 * (G.box_max_width - G.box_min_width);
+                    height[k] = (out[2] * 0.5 * (G.box_max_height - G.box_min_height)) + 0.5 * (G.box_max_height - G.box_min_height);
+                    angle[k] = G.box_min_angle + (((out[4] + 1.0) * 0.5) * (G.box_max_angle - G.box_min_angle));
+                    height[k] = pymin(pymax(height[k], G.box_min_height), G.box_max_height);
+                    width[k] = pymin(pymax(width[k], G.box_min_width), G.box_max_width);
+                    angle[k] = pymin(pymax(angle[k], G.box_min_angle), G.box_max_angle);
+                } else {
+                    radius[k] = out[2] + 1.5;
+                    angle[k] = G.circle_min_angle + (((out[4] + 1.0) * 0.5) * (G.circle_max_angle - G.circle_min_angle));
+                    radius[k] = pymin(pymax(radius[k], G.circle_min_radius), G.circle_max_radius);
+                    angle[k] = pymin(pymax(angle[k], G.circle_min_angle), G.circle_max_angle);
+                }
+                // ctrl = deepcopy(moduleList[ref].controller); ctrl.setControl(out[5..8], moduleList[ref].angle)
+                const double pangle = proto(G.mod_angle, ref);
+                amp[k] = ((out[5] + 1.0) * 0.5) * G.ctl_max_amp;
+                phase[k] = out[6] * G.ctl_max_phase;
+                offset[k] = out[7] * G.ctl_max_offset;
+                freq[k] = out[8] * G.ctl_max_freq;
+                amp[k] = pymin(pymax(amp[k], 0.0), G.ctl_max_amp);
+                phase[k] = pymin(pymax(phase[k], -G.ctl_max_phase), G.ctl_max_phase);
+                freq[k] = pymin(pymax(freq[k], -G.ctl_max_freq), G.ctl_max_freq);
+                if (offset[k] > pangle / 2) offset[k] = pangle / 2;
+                else if (offset[k] < -pangle / 2) offset[k] = -pangle / 2;
+                pool[s].child[pool[s].nChild++] = k;
+                index += 1;
+            }
+        }
+        return index;
+    }
+    int grow(int s, int index, int depth) {
+        if (!pool[s].handled) {
+            pool[s].handled = true;
+            index = query(index, s, depth);
+        } else {
+            for (int c = 0; c < pool[s].nChild; ++c) index = grow(pool[s].child[c], index, depth + 1);
+        }
+        return index;
+    }
+    int emit(int parentIndex, int s, TreeNode *nodes, int *symOf, int &nNodes, int counter) {
+        if (counter > 20) return counter; // MAX_MODULES of the emitter (Network_Encoding.py / encodings/network.py)
+        if (nNodes >= MAXN) { overflow = true; return counter; }
+        nodes[nNodes].index = pool[s].index; nodes[nNodes].parent = parentIndex;
+        nodes[nNodes].type = nNodes; nodes[nNodes].site = pool[s].site;
+        symOf[nNodes] = s;
+        ++nNodes;
+        for (int c = 0; c < pool[s].nChild; ++c) {
+            counter += 1;
+            counter = emit(pool[pool[s].child[c]].parent, pool[s].child[c], nodes, symOf, nNodes, counter);
+        }
+        return counter;
+    }
+    int create(TreeNode *nodes, int *symOf) {
+        // base = _Symbol(0, moduleList[0], -1): a copy of prototype 0 (no setMorph), its prototype controller
+        nPool = 1;
+        NetSym &b = pool[0];
+        b.index = 0; b.parent = -1; b.ref = -1; b.site = -1; b.handled = false; b.nChild = 0; b.node = -1;
+        shape[0] = G.mod_shape[(size_t)e * T + 0];
+        width[0] = proto(G.mod_width, 0); height[0] = proto(G.mod_height, 0); radius[0] = proto(G.mod_radius, 0);
+        angle[0] = proto(G.mod_angle, 0); torque[0] = proto(G.mod_torque, 0);
+        amp[0] = proto(G.ctl_amp, 0); phase[0] = proto(G.ctl_phase, 0); freq[0] = proto(G.ctl_freq, 0); offset[0] = proto(G.ctl_offset, 0);
+        int index = 1;
+        for (int d = 0; d < maxDepth; ++d) index = grow(0, index, 0);
+        int nNodes = 0;
+        emit(-1, 0, nodes, symOf, nNodes, 0);
+        return nNodes;
+    }
+};
+
+} // namespace rem2d_host
+
+extern "C" int rem2d_compile_network(const rem2d_network_genomes *G, int32_t tree_depth, double terrain_height, int32_t lanes,
+                                     const rem2d_morph *out, int32_t *n_bodies, int32_t n_threads) {
+    using namespace rem2d_host;
+    if (!G || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (G->n_types <= 0 || G->n_types > 64) return fail(REM2D_E_INVALID, "n_types must be 1..64");
+    if (G->n_hidden <= 0 || G->n_hidden > 64) return fail(REM2D_E_INVALID, "n_hidden must be 1..64");
+    if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
+    if (tree_depth <= 0) return fail(REM2D_E_INVALID, "tree_depth must be positive");
+    const int n = G->n;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads > n) n_threads = n > 0 ? n : 1;
+    const float lower = (float)(-PI / 2), upper = (float)(PI / 2);
+    std::vector<int> status((size_t)(n_threads > 0 ? n_threads : 1), 0);
+    auto work = [&](int tid) {
+        const int per = (n + n_threads - 1) / n_threads;
+        const int e0 = tid * per, e1 = e0 + per < n ? e0 + per : n;
+        std::vector<NetExpander> holder; // the expander is large: keep it off the thread's stack
+        for (int e = e0; e < e1; ++e) {
+            holder.clear();
+            holder.emplace_back(*G, e, tree_depth);
+            NetExpander &ex = holder[0];
+            TreeNode nodes[MAXN];
+            int symOf[MAXN];
+            const int nNodes = ex.create(nodes, symOf);
+            // per-node parameter tables for build_creature (type = node position)
+            int32_t nshape[MAXN];
+            double nw[MAXN], nh[MAXN], nr[MAXN], na[MAXN], nt[MAXN], camp[MAXN], cph[MAXN], cfr[MAXN], cof[MAXN];
+            for (int i = 0; i < nNodes; ++i) {
+                const int s = symOf[i];
+                nshape[i] = ex.shape[s]; nw[i] = ex.width[s]; nh[i] = ex.height[s]; nr[i] = ex.radius[s]; na[i] = ex.angle[s];
+                nt[i] = ex.torque[s]; camp[i] = ex.amp[s]; cph[i] = ex.phase[s]; cfr[i] = ex.freq[s]; cof[i] = ex.offset[s];
+            }
+            Genome g;
+            g.nTypes = nNodes;
+            g.shape = nshape; g.width = nw; g.height = nh; g.radius = nr; g.angle = na; g.torque = nt;
+            g.amp = camp; g.phase = cph; g.freq = cfr; g.offset = cof;
+            g.ruleN = nullptr; g.ruleSite = nullptr; g.ruleRef = nullptr;
+            Creature cr;
+            build_creature(g, nodes, nNodes, terrain_height, cr);
+            if (ex.overflow || cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
+            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
+            n_bodies[e] = cr.nBodies;
+        }
+    };
+    if (n_threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    for (int s : status)
+        if (s) return fail(REM2D_E_INVALID, "a creature has more bodies than `lanes` (n_bodies = -1 marks it)");
+    return REM2D_OK;
+}
+
 #endif

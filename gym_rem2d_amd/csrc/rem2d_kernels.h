@@ -526,32 +526,23 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_multi_kernel(Batch B, Step
 //                           time-transparent), so the list order does not matter.
 // reward / done / fitness only read the root body: whichever kernel finalises the root does the bookkeeping.
 // =====================================================================================
-template <int K>
-DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
-    const int lane = threadIdx.x;
-    const unsigned gl = block * WAVE + lane;
-    const unsigned env = gl / K;
-    const int sub = lane & (K - 1);
+// the scan for one body (its final pose of the discrete step in registers or freshly loaded): invalidate the TOI flags of
+// its pairs, apply the exact early-outs, then either queue the body for the TOI solve or -- for a root -- finish the step
+DEV void toi_scan_lane(const State &S, const Terrain &T, float dt, unsigned gl, unsigned env, int sub, int shape, float px,
+                       float py, float ang, float c0x, float c0y, float a0, float hx, float hy, int awake, int cCount) {
     const unsigned Lp = S.Lp;
-    if (S.flags & REM2D_FLAG_SKIP_FROZEN) {
-        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return; // the step kernel skipped this wavefront too
-    }
-    const int shape = LI(L_SHAPE);
-    const float px = LF(L_PX);
     bool heavy = false;
-    if (shape != SHAPE_NONE && A.dt > 0.0f) {
-        const unsigned wb = (unsigned)SCR_SWEEP_BASE * Lp + gl;
+    if (shape != SHAPE_NONE && dt > 0.0f) {
         Sweep sw;
-        sw.c0 = mk(SW(wb, 0), SW(wb, 1)); sw.a0 = SW(wb, 2);
-        sw.c = mk(px, LF(L_PY)); sw.a = LF(L_ANG);
-        const float hx = LF(L_HX), hy = LF(L_HY);
-        const int awake = LI(L_AWAKE), cCount = LI(L_CCOUNT);
+        sw.c0 = mk(c0x, c0y); sw.a0 = a0;
+        sw.c = mk(px, py); sw.a = ang;
         const Proxy pB = proxy_body(shape, hx, hy);
         const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f;
         for (int s = 0; s < cCount; ++s) {
             unsigned o = (unsigned)s * Lp + gl;
-            int info = CI(C_INFO, o) & (0xffff | CI_ENABLED); // m_stepComplete: invalidate TOIs
-            CI(C_INFO, o) = info;
+            const int old = CI(C_INFO, o);
+            const int info = old & (0xffff | CI_ENABLED); // m_stepComplete: invalidate TOIs
+            if (info != old) CI(C_INFO, o) = info;
             if (!(info & CI_ENABLED) || !awake || heavy) continue;
             int e = CI(C_EDGE, o);
             Proxy pA = proxy_edge(static_vert(T, e, 0), static_vert(T, e, 1));
@@ -565,6 +556,20 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
     } else if (sub == 0) {
         env_bookkeeping(S, env, 0, px);
     }
+}
+template <int K>
+DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
+    const int lane = threadIdx.x;
+    const unsigned gl = block * WAVE + lane;
+    const unsigned env = gl / K;
+    const int sub = lane & (K - 1);
+    const unsigned Lp = S.Lp;
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) {
+        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return; // the step kernel skipped this wavefront too
+    }
+    const unsigned wb = (unsigned)SCR_SWEEP_BASE * Lp + gl;
+    toi_scan_lane(S, T, A.dt, gl, env, sub, LI(L_SHAPE), LF(L_PX), LF(L_PY), LF(L_ANG), SW(wb, 0), SW(wb, 1), SW(wb, 2),
+                  LF(L_HX), LF(L_HY), LI(L_AWAKE), LI(L_CCOUNT));
 }
 template <int K>
 DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, ToiShared &ts) {

@@ -331,6 +331,9 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
         EI(E_POSITERS) = lastPosIters;
     }
     if (!A.defer) env_bookkeeping(S, env, sub, __shfl(px, base));
+    // continuous physics: the TOI scan of this body, with its pose and sweep start still in registers (it was a kernel
+    // of its own: one launch, one grid of early-exits and a round trip of the sweep start through HBM less per step)
+    else if (A.defer == 2) toi_scan_lane(S, T, A.dt, gl, env, sub, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
 }
 
 template <int K>

@@ -263,3 +263,86 @@ def encode_trees_native(individuals, tree_depth=None, n_threads=0):
     M = arrays["index"].shape[1]
     lanes = 64 if M > 32 else lanes_for(M)
     return batches_from_compiled(compile_tree_arrays(arrays, lanes, n_threads))
+
+
+# ------------------------------------------------------------------------------------------------
+# native path for network genomes: the NN queries that grow the tree run in rem2d_compile_network too
+# ------------------------------------------------------------------------------------------------
+_PROTO_F64 = ("mod_width", "mod_height", "mod_radius", "mod_angle", "mod_torque", "ctl_amp", "ctl_phase", "ctl_freq",
+              "ctl_offset")
+
+
+def network_genome_arrays(genomes):
+    """SoA view of a list of ``NNEncoding`` genomes with ``FeedForwardCPPN`` networks: weights, activation ids and the
+    (mutated) module prototypes each genome carries."""
+    n = len(genomes)
+    T = len(genomes[0].moduleList) if n else 0
+    H = genomes[0].nn_g.n_hidden if n else 0
+    a = dict(w1=np.zeros((n, H, 4)), a1=np.zeros((n, H), np.int32), w2=np.zeros((n, 10, H + 1)),
+             mod_shape=np.zeros((n, T), np.int32))
+    for k in _PROTO_F64:
+        a[k] = np.zeros((n, T), np.float64)
+    for e, g in enumerate(genomes):
+        net = g.nn_g
+        if len(g.moduleList) != T or net.n_hidden != H or net.n_inputs != 3 or net.n_outputs != 10:
+            raise ValueError("all genomes of one batch must share module count and network shape (3 -> H -> 10)")
+        a["w1"][e], a["a1"][e], a["w2"][e] = net.w1, net.a1, net.w2
+        for t, m in enumerate(g.moduleList):
+            box = m.type == "SIMPLE"
+            a["mod_shape"][e, t] = 1 if box else 2
+            if box:
+                a["mod_width"][e, t], a["mod_height"][e, t] = m.width, m.height
+            else:
+                a["mod_radius"][e, t] = m.radius
+            a["mod_angle"][e, t], a["mod_torque"][e, t] = m.angle, m.torque
+            c = m.controller
+            a["ctl_amp"][e, t], a["ctl_phase"][e, t], a["ctl_freq"][e, t], a["ctl_offset"][e, t] = \
+                c.amplitude, c.phase, c.frequency, c.offset
+    return a
+
+
+def compile_network_arrays(arrays, tree_depth, max_modules, lanes, n_threads=0):
+    """rem2d_compile_network on genome arrays -> Morphology with `lanes` lanes per creature."""
+    import ctypes as C
+    from . import _lib
+    from .compiler import TERRAIN_HEIGHT
+    from .controller import Controller
+    from .modules import Circular2D, Standard2D
+    n, T = arrays["mod_shape"].shape
+    m = Morphology(n, lanes)
+    G = _lib.NetworkGenomes()
+    G.n, G.n_types, G.n_hidden, G.max_modules = int(n), int(T), int(arrays["a1"].shape[1]), int(max_modules)
+    keep = []
+    for k in ("w1", "a1", "w2", "mod_shape") + _PROTO_F64:
+        v = np.ascontiguousarray(arrays[k])
+        keep.append(v)
+        setattr(G, k, v.ctypes.data_as(C.c_void_p))
+    # the classes' constants are handed over, not restated in C++
+    G.box_min_width, G.box_max_width = Standard2D.MIN_WIDTH, Standard2D.MAX_WIDTH
+    G.box_min_height, G.box_max_height = Standard2D.MIN_HEIGHT, Standard2D.MAX_HEIGHT
+    G.box_min_angle, G.box_max_angle = Standard2D.MIN_ANGLE, Standard2D.MAX_ANGLE
+    G.circle_min_radius, G.circle_max_radius = Circular2D.MIN_RADIUS, Circular2D.MAX_RADIUS
+    G.circle_min_angle, G.circle_max_angle = Circular2D.MIN_ANGLE, Circular2D.MAX_ANGLE
+    G.ctl_max_amp, G.ctl_max_phase = Controller.MAX_AMP, Controller.MAX_PHASE
+    G.ctl_max_offset, G.ctl_max_freq = Controller.MAX_OFFSET, Controller.MAX_FREQ
+    out = _lib.Morph()
+    for k in m.arrays:
+        setattr(out, k, m.arrays[k].ctypes.data_as(C.c_void_p))
+    _lib.check(_lib.lib().rem2d_compile_network(C.byref(G), int(tree_depth), float(TERRAIN_HEIGHT), int(lanes), C.byref(out),
+                                                m.n_bodies.ctypes.data_as(C.c_void_p), int(n_threads)))
+    return m
+
+
+def encode_network_native(individuals, tree_depth=None, n_threads=0):
+    """Same result as encode_population for ``NNEncoding`` genomes (feed-forward CPPN): tree growth by network queries
+    (Network_Encoding.py:86-139,171-206), create_robot, schedule and packing all natively."""
+    genomes = [ind.genome for ind in individuals]
+    if not genomes:
+        return []
+    depth = tree_depth if tree_depth is not None else individuals[0].tree_depth
+    maxm = genomes[0].maxModules
+    if any(g.maxModules != maxm for g in genomes):
+        raise ValueError("genomes of one batch must share maxModules")
+    arrays = network_genome_arrays(genomes)
+    lanes = 32   # the emitter stops at MAX_MODULES = 20 (+ the root): at most 22 nodes
+    return batches_from_compiled(compile_network_arrays(arrays, depth, maxm, lanes, n_threads))

@@ -116,6 +116,12 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
         # L-system genomes: native compiler (no fork, ~30 us per individual incl. reading the objects)
         from .encode import encode_lsystem_native
         batches = encode_lsystem_native(individuals, n_threads=workers or 0)
+    elif individuals and all(_is_ff_network(ind.genome) for ind in individuals) and \
+            len({ind.genome.maxModules for ind in individuals}) == 1:
+        # network genomes (feed-forward CPPN): the NN queries that grow the tree run natively as well
+        from .encode import encode_network_native
+        depth = tree_depth if tree_depth is not None else individuals[0].tree_depth
+        batches = encode_network_native(individuals, depth, n_threads=workers or 0)
     else:
         # every other encoding: python hands out the phenotype trees, the native compiler builds the creatures
         from .encode import encode_trees_native
@@ -125,6 +131,11 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
     if own:
         env.close()
     return fit
+
+
+def _is_ff_network(genome):
+    from .encodings.network import FeedForwardCPPN, NNEncoding
+    return type(genome) is NNEncoding and type(genome.nn_g) is FeedForwardCPPN
 
 
 def shard_range(n, rank, world_size):

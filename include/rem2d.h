@@ -208,6 +208,27 @@ typedef struct {
 int rem2d_compile_trees(const rem2d_tree_batch *trees, double terrain_height, int32_t lanes, const rem2d_morph *out,
                         int32_t *n_bodies, int32_t n_threads);
 
+/* The network encoding end to end (Encodings/Network_Encoding.py:42-222: update / iterate / create / recursiveNodeGen --
+ * one network query per free connection site decides whether a child exists, its module type, shape (setMorph,
+ * simple_module.py:86-93, circular_module.py) and controller (setControl, m_controller.py)), then create_robot as above.
+ * The network is this build's synthetic feed-forward CPPN (neat-python is absent): 3 inputs, n_hidden nodes with one of
+ * four activations (0 tanh, 1 sin, 2 gauss-like exp(-x^2)*2-1, 3 clamp), 10 tanh outputs.  HOST pointers. */
+typedef struct {
+    int32_t n, n_types, n_hidden, max_modules; /* genomes, module prototypes per genome, hidden nodes, NNEncoding.maxModules */
+    const double *w1;                          /* [n][n_hidden][4]  (3 inputs + bias) */
+    const int32_t *a1;                         /* [n][n_hidden]     activation id */
+    const double *w2;                          /* [n][10][n_hidden + 1] */
+    const int32_t *mod_shape;                  /* [n][n_types] prototypes (genome.moduleList), as in rem2d_lsystem_genomes */
+    const double *mod_width, *mod_height, *mod_radius, *mod_angle, *mod_torque;
+    const double *ctl_amp, *ctl_phase, *ctl_freq, *ctl_offset;
+    /* class constants of the module / controller classes (simple_module.py:33-39, circular_module.py, m_controller.py:9-12) */
+    double box_min_width, box_max_width, box_min_height, box_max_height, box_min_angle, box_max_angle;
+    double circle_min_radius, circle_max_radius, circle_min_angle, circle_max_angle;
+    double ctl_max_amp, ctl_max_phase, ctl_max_offset, ctl_max_freq;
+} rem2d_network_genomes;
+int rem2d_compile_network(const rem2d_network_genomes *genomes, int32_t tree_depth, double terrain_height, int32_t lanes,
+                          const rem2d_morph *out, int32_t *n_bodies, int32_t n_threads);
+
 /* Population diversity (DataAnalysis/AdvancedDataAnalysis.py:291-313 compare_distance, :367-381
  * tree_edit_distance): out[c] = sum over t != c of the number of nodes of c whose (x, y) position does not
  * occur in t plus the number of nodes of t that no node of c sits on; positions are binary64 and compared

@@ -148,3 +148,26 @@ def test_native_tree_compiler_errors(built):
     bad["node_count"][0] = 1000
     with pytest.raises(_lib.Rem2dError, match="node_count"):
         built.compile_tree_arrays(bad, 32)
+
+
+@pytest.mark.parametrize("depth", [7, 4])
+def test_native_network_expansion_equals_python(built, depth):
+    """rem2d_compile_network: the NN-query tree growth of the network encoding (Network_Encoding.py:86-139,171-206:
+    update / iterate / create / recursiveNodeGen, setMorph, setControl) + create_robot, all native, vs the Python
+    path word for word -- incl. mutated prototypes and mutated networks."""
+    from gym_rem2d_amd.ea import Individual
+    random.seed(123)
+    inds = [Individual.random(encoding="cppn") for _ in range(400)]
+    for k, ind in enumerate(inds):
+        for _ in range(k % 4):
+            ind.mutate(0.4, 0.4, 0.3)
+    py = built.encode_population(inds, depth, workers=1)
+    nat = built.encode_network_native(inds, depth, n_threads=3)
+    assert [b[0].lanes for b in py] == [b[0].lanes for b in nat]
+    for (mp, ip), (mn, in_) in zip(py, nat):
+        assert ip == in_
+        assert np.array_equal(mp.n_bodies, mn.n_bodies)
+        for k in mp.arrays:
+            assert np.array_equal(mp.arrays[k], mn.arrays[k]), (k, depth)
+    sizes = np.concatenate([b[0].n_bodies for b in nat])
+    assert len(sizes) == 400 and sizes.max() >= 6 and len(np.unique(sizes)) >= 4   # the population is varied
