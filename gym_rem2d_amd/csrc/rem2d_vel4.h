@@ -441,6 +441,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         const bool stamp = (V4_DBG(A) & 8) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py)
         unsigned long long tJ = 0, tC = 0, t0 = 0, t1 = 0, nSub = 0;
         const unsigned long long tStart = stamp ? __builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long rStart = stamp ? __builtin_amdgcn_s_memrealtime() : 0; // constant 100 MHz
         for (int base = 0; base < nTicks; base += P) {
 #pragma unroll
             for (int s = 0; s < V4_PHASES; ++s) {
@@ -466,6 +467,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             env = (unsigned)c0 + 2; EI(E_TOIEVENTS) = (int)(tAll >> 4);
             env = (unsigned)c0 + 3; EI(E_TOIEVENTS) = (int)nSub;
             env = (unsigned)c0 + 4; EI(E_TOIEVENTS) = nTicks;
+            if (c1 - c0 >= 6) { env = (unsigned)c0 + 5; EI(E_TOIEVENTS) = (int)(__builtin_amdgcn_s_memrealtime() - rStart); }
         }
     }
     // ---------------- StoreImpulses, joint impulses, body velocities ----------------

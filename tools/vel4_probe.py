@@ -79,6 +79,10 @@ for m in morphs:
         t = w.tiles[:-1]
         t = t[(np.diff(w.tiles) >= 5) & (t + 5 <= m.n_envs)]
         tj, tc, ta, ns, nk = (ev[t + i].astype(np.float64) for i in range(5))
+        t6 = w.tiles[:-1][(np.diff(w.tiles) >= 6) & (w.tiles[:-1] + 6 <= m.n_envs)]
+        if len(t6):
+            real = ev[t6 + 5].astype(np.float64)            # 100 MHz ticks of the loop
+            print("   shader clock inside the loop: %.2f GHz (s_memtime / s_memrealtime)" % ((ev[t6 + 2].astype(np.float64) * 16 / real).mean() * 0.1))
         print("   s_memtime per tile (cycles): joint slots %.0f  contact sub-slots %.0f  loop %.0f | ticks %.0f  sub-slots %.0f -> "
               "%.0f cycles/joint slot, %.0f cycles/sub-slot" % (tj.mean() * 16, tc.mean() * 16, ta.mean() * 16, nk.mean(), ns.mean(),
               (tj * 16 / nk).mean(), (tc * 16 / np.maximum(ns, 1)).mean()))
