@@ -123,6 +123,7 @@ def lib():
                                           C.c_float]
     L.rem2d_world_reset.argtypes = [C.c_void_p, C.POINTER(Morph), C.c_void_p]
     L.rem2d_world_set_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.rem2d_world_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rem2d_plan_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]

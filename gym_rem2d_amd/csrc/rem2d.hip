@@ -156,6 +156,9 @@ static void bind_state(rem2d_world *w) {
     S.Np = (unsigned)L.Np;
     S.nEnvs = (unsigned)w->cfg.n_envs;
     S.flags = w->cfg.flags;
+    S.outReward = nullptr;
+    S.outDone = nullptr;
+    S.outIndex = nullptr;
 }
 
 extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, size_t state_bytes, rem2d_world **out) {
@@ -219,6 +222,16 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         }
     }
     *out = w;
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_t *done_dev, const int32_t *index_dev) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if ((reward_dev == nullptr) != (done_dev == nullptr) || (reward_dev == nullptr) != (index_dev == nullptr))
+        return fail(REM2D_E_INVALID, "set_outputs: pass all three pointers, or three NULLs to switch it off");
+    w->S.outReward = reward_dev;
+    w->S.outDone = done_dev;
+    w->S.outIndex = index_dev;
     return REM2D_OK;
 }
 

@@ -16,6 +16,11 @@ DEV void env_bookkeeping(const State &S, unsigned env, int sub, float rootx) {
     if (wod > r) { rew = -100.0; d = 1; }
     EF(E_REWARD) = (float)rew;
     EI(E_DONE) = d;
+    if (S.outIndex && env < S.nEnvs) { // population-order outputs: no gather kernels on the host side
+        const int g = S.outIndex[env];
+        S.outReward[g] = (float)rew;
+        S.outDone[g] = (unsigned char)d;
+    }
     if (d) EI(E_EVERDONE) = 1;
     int stepIdx = EI(E_STEPS);
     if (!EI(E_FROZEN)) {

@@ -81,6 +81,11 @@ struct State {
     float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
     int *toiWork;                              // handle-owned: [0] count, [16..16+Lp) bodies that need the full TOI solve
     const int *tiles;                          // handle-owned: tile t of the velocity kernel = creatures [tiles[t], tiles[t+1])
+    // optional, caller-owned (rem2d_world_set_outputs): reward / done of creature e also go to outReward[outIndex[e]] /
+    // outDone[outIndex[e]] -- the population-order arrays of a population that lives in several worlds
+    float *outReward;
+    unsigned char *outDone;
+    const int *outIndex;
     unsigned Lp, Np, nEnvs, flags;
 };
 // accessors (S, gl and env must be in scope where they are used)

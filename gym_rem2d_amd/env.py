@@ -156,6 +156,11 @@ class BatchedModular2D:
         self._reward = torch.zeros(n_envs, dtype=torch.float32, device=dev)
         self._done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
         self._fitness = torch.zeros(n_envs, dtype=torch.float64, device=dev)
+        if len(self.worlds) > 1:
+            # the kernels write reward / done straight into these population-order arrays (rem2d_world_set_outputs):
+            # step() returns them without a gather per world
+            for w, idx in self.worlds:
+                w.set_outputs(self._reward, self._done, idx.to(torch.int32))
 
     def _bind_views(self):
         """Let node.component / robot.components read live poses (host read-back; API parity only)."""
@@ -205,10 +210,7 @@ class BatchedModular2D:
         if len(self.worlds) == 1:
             w = self.worlds[0][0]
             return w.view("reward"), w.view("done") != 0
-        for w, idx in self.worlds:
-            self._reward.index_copy_(0, idx, w.view("reward"))
-            self._done.index_copy_(0, idx, w.view("done") != 0)
-        return self._reward, self._done
+        return self._reward, self._done   # written by the step's own kernels (set_outputs in _upload)
 
     def _gather(self, name, out):
         if len(self.worlds) == 1:

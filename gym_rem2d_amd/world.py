@@ -79,6 +79,12 @@ class BatchedWorld:
                                      self.n_envs_padded)
         _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
+    def set_outputs(self, reward, done, index):
+        """Let the kernels also write reward / done of creature e to reward[index[e]] / done[index[e]] (population
+        order; `done` is a torch.bool tensor, `index` int32 on the device).  The tensors are kept alive here."""
+        self._outputs = (reward, done, index)
+        _lib.check(_lib.lib().rem2d_world_set_outputs(self.h, reward.data_ptr(), done.data_ptr(), index.data_ptr()))
+
     def step(self, n_steps=1):
         _lib.check(_lib.lib().rem2d_world_step(self.h, int(n_steps), self._stream()))
 

@@ -132,6 +132,13 @@ int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, in
  * robots (create_robot :517-563) from the uploaded layout; wall of death back to 0. */
 int rem2d_world_reset(rem2d_world *w, const rem2d_morph *morph_dev, void *stream);
 
+/* A population that lives in several worlds (one per lane count) reads reward / done in POPULATION order: with these
+ * caller-owned device arrays set, every env-step also writes creature e's reward (float) and done (0 / 1 byte, the
+ * storage of a torch.bool tensor) to reward_dev[index_dev[e]] / done_dev[index_dev[e]] -- what `step()` returns
+ * (Modular2DEnv.py:642-653) without a gather per world on the host side.  index_dev: [n_envs] int32.  Three NULLs
+ * switch it off.  The arrays must outlive the world or be reset before they are freed. */
+int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_t *done_dev, const int32_t *index_dev);
+
 /* Work partition of the velocity kernel (no counterpart in the reference: Box2D walks one island at a time,
  * b2World::Solve).  The 180 velocity iterations of world.Step (Modular2DEnv.py:634) run one TILE per wavefront: tile t
  * = creatures [tile_start[t], tile_start[t+1]).  Rules, checked here or flagged as REM2D_ERR_SOLVER_OVERFLOW by the

@@ -248,3 +248,28 @@ def test_state_dump_for_external_viewers(need_gpu, tmp_path):
     prims = statedump.frame_to_draw_list(head, frames[-1])
     assert len(prims) == 2 and sum(p[0] in ("polygon", "circle") for p in prims[0]) == specs[0].n_bodies
     env.close()
+
+
+def test_step_returns_population_order_reward_and_done(need_gpu):
+    """A mixed population lives in one world per lane count (and several step groups); the kernels write reward / done
+    straight into population-order arrays (rem2d_world_set_outputs), so what step() returns (Modular2DEnv.py:642-653)
+    equals the per-world fields gathered by hand -- in every step, with no gather kernels on the way."""
+    import torch
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(300))
+    env = BatchedModular2D()
+    env.reset_specs(specs)
+    assert len(env.worlds) >= 3
+    for n in (1, 1, 7, 40, 130):
+        reward, done = env.step(n)
+        torch.cuda.synchronize()
+        ref_r = torch.zeros_like(reward)
+        ref_d = torch.zeros_like(done)
+        for w, idx in env.worlds:
+            ref_r[idx] = w.view("reward")
+            ref_d[idx] = w.view("done") != 0
+        assert reward.dtype == torch.float32 and done.dtype == torch.bool and reward.shape == (300,)
+        assert torch.equal(reward, ref_r) and torch.equal(done, ref_d)
+    assert bool(done.any()) and not bool(done.all())      # the wall of death has caught some creatures by step 179
+    env.close()
