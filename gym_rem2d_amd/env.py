@@ -306,7 +306,46 @@ class Modular2D(gymshim.Env):
         return 0, (r if not d else -100), (True if d else 0), 0
 
     def render(self, mode='human'):
-        raise NotImplementedError("rendering is outside the accelerated path (SURVEY.md section 2)")
+        """The reference paints into a pyglet window (Modular2DEnv.py:655-738; pyglet is not a dependency here).
+        ``mode='rgb_array'`` returns the same picture -- terrain, module boxes / circles, joint anchors, wall of death,
+        camera following the root -- as an ``[H, W, 3] uint8`` array drawn with matplotlib (Agg) from a state dump of
+        the current step; ``mode='human'`` is refused (no window system on this path)."""
+        if mode != 'rgb_array':
+            raise NotImplementedError("only mode='rgb_array' is available (no pyglet window on the accelerated path); "
+                                      "statedump.record_episode + tools/render_dump.py write whole runs")
+        if self._batch is None:
+            raise Exception("no tree_morphology")
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        from matplotlib.patches import Circle, Polygon
+        from . import statedump
+        head = statedump.header(self._batch, [0])
+        fr = statedump.frame(self._batch, [0], 0)
+        prims = statedump.frame_to_draw_list(head, fr)[0]
+        cx = fr["creatures"][0]["pose"][0][0]
+        fig, ax = plt.subplots(figsize=(VIEWPORT_W / 100.0, VIEWPORT_H / 100.0), dpi=100)
+        ax.plot(head["terrain"]["x"], head["terrain"]["y"], color="#356635", lw=1.5)
+        for box in head["terrain"]["boxes"]:
+            ax.add_patch(Polygon(box, closed=True, color="#444444"))
+        for p in prims:
+            if p[0] == "polygon":
+                ax.add_patch(Polygon(p[1], closed=True, facecolor="#7fa6d9", edgecolor="#1f3f66"))
+            elif p[0] == "circle":
+                ax.add_patch(Circle(p[1], p[2], facecolor="#d9a67f", edgecolor="#66401f"))
+            else:
+                ax.plot([p[1][0]], [p[1][1]], "k.", ms=3)
+        ax.axvline(fr["creatures"][0]["wall_of_death"], color="red", lw=1)
+        half = VIEWPORT_W / SCALE / 2
+        ax.set_xlim(cx - half, cx + half)
+        ax.set_ylim(0, VIEWPORT_H / SCALE)
+        ax.set_aspect("equal")
+        ax.axis("off")
+        fig.subplots_adjust(0, 0, 1, 1)
+        fig.canvas.draw()
+        img = np.asarray(fig.canvas.buffer_rgba())[..., :3].copy()
+        plt.close(fig)
+        return img
 
     def close(self):
         if self._batch is not None:
