@@ -116,14 +116,14 @@ struct rem2d_world {
 
 // Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
-//   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3)   2: the same at 5 waves/SIMD (spills)
+//   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
 struct TileShape { int sets, passes, csets; };
 static int tile_shape_id() {
     static const int id = getenv("REM2D_TILE_SHAPE") ? atoi(getenv("REM2D_TILE_SHAPE")) : 3;
-    return id < 0 || id > 3 ? 3 : id;
+    return (id == 0 || id == 1) ? id : 3;
 }
 static TileShape tile_shape() {
-    static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}};
+    static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}}; // [2] unused
     return shapes[tile_shape_id()];
 }
 
@@ -200,13 +200,14 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMemset(scratch): ") + hipGetErrorString(e));
     }
-    // default tiles of the velocity kernel: 128 / lanes creatures each.  The joints of one schedule phase of a creature
-    // are a matching of its tree (<= lanes / 2 of them), so such a tile never has more than 64 joints in a phase;
+    // default tiles of the velocity kernel.  The joints of one schedule phase of a creature are a matching of its tree
+    // (<= lanes / 2 of them), so 128 / lanes creatures never have more than 64 joints in a phase;
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
     {
         // (with one joint set per lane a tile holds at most 64 joints: 64 / lanes creatures)
         const TileShape shp = tile_shape();
-        int per = (shp.sets >= 2 ? 128 : 64) / cfg->lanes;
+        // 4 sets = one phase per set: 128 / lanes creatures; fewer sets share phases, so keep to 64 joints in all
+        int per = (shp.sets >= V4_PHASES ? 128 : 64) / cfg->lanes;
         if (per * cfg->lanes > shp.passes * WAVE) per = shp.passes * WAVE / cfg->lanes;
         if (per < 1) per = 1;
         std::vector<int32_t> ts;
@@ -574,7 +575,6 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         switch (tile_shape_id()) {
         case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
-        case 2: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 5>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         }
         if (timed) w0->evUsed += 1;
