@@ -1893,6 +1893,19 @@ void rem2d_oracle_probe_toi(int *out, int reset) {
 void rem2d_oracle_probe_hist(int *out, int reset) {
     for (int i = 0; i < 512; ++i) { out[i] = g_probe_hist[i]; if (reset) g_probe_hist[i] = 0; }
 }
+/* position iterations: [0..63] iterations used by islands that passed the tolerance test; [64..127] iteration at which an
+ * island that never passes it stopped changing any bit of any position (127 = never); [128] contacts failing at the last
+ * iteration, [129] joints failing, [130] both */
+static int g_probe_pos[160];
+void rem2d_oracle_probe_pos(int *out, int reset) {
+    for (int i = 0; i < 160; ++i) { out[i] = g_probe_pos[i]; if (reset) g_probe_pos[i] = 0; }
+}
+static int probe_pos_snapshot(island_t *is, int which) {
+    f32 *o = t_probe[which];
+    int n = 0;
+    for (int i = 0; i < is->nbody; ++i) { o[n++] = is->positions[i].c.x; o[n++] = is->positions[i].c.y; o[n++] = is->positions[i].a; }
+    return which == 1 && memcmp(t_probe[0], t_probe[1], (size_t)n * sizeof(f32)) == 0;
+}
 #endif
 
 static void island_solve(o_world *w, island_t *is, const step_t *step) {
@@ -1960,19 +1973,36 @@ static void island_solve(o_world *w, island_t *is, const step_t *step) {
     }
     int positionSolved = 0;
     w->lastPositionIterations = step->positionIterations;
+#ifdef REM2D_ORACLE_PROBE
+    int probeFixed = -1, probeC = 1, probeJ = 1;
+#endif
     for (int it = 0; it < step->positionIterations; ++it) {
+#ifdef REM2D_ORACLE_PROBE
+        probe_pos_snapshot(is, 0);
+#endif
         int contactsOkay = contact_solver_solve_position(is);
         int jointsOkay = 1;
         for (int i = 0; i < is->njoint; ++i) {
             int jointOkay = joint_solve_position(is, &w->joints[is->joints[i]]);
             jointsOkay = jointsOkay && jointOkay;
         }
+#ifdef REM2D_ORACLE_PROBE
+        if (probeFixed < 0 && probe_pos_snapshot(is, 1)) probeFixed = it;
+        probeC = contactsOkay; probeJ = jointsOkay;
+#endif
         if (contactsOkay && jointsOkay) {
             positionSolved = 1;
             w->lastPositionIterations = it + 1;
             break;
         }
     }
+#ifdef REM2D_ORACLE_PROBE
+    if (positionSolved) __atomic_fetch_add(&g_probe_pos[w->lastPositionIterations < 63 ? w->lastPositionIterations : 63], 1, __ATOMIC_RELAXED);
+    else {
+        __atomic_fetch_add(&g_probe_pos[64 + (probeFixed < 0 ? 63 : probeFixed)], 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_probe_pos[!probeC && !probeJ ? 130 : !probeC ? 128 : 129], 1, __ATOMIC_RELAXED);
+    }
+#endif
     for (int i = 0; i < is->nbody; ++i) {
         body_t *b = &w->bodies[is->bodies[i]];
         b->c = is->positions[i].c;
