@@ -70,6 +70,22 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
+def valu_issue(n_groups):
+    """VALU wave-instructions per env-step of the default population from the committed SQ-counter pass
+    (profiles/r02_b_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
+    measured issue peak (tools/ubench_latency.hip -> profiles/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s)."""
+    path = os.path.join(ROOT, "profiles", "r02_b_sq_counters.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception:  # noqa: BLE001
+        return None
+    per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
+                    if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi")))
+    return {"wave_instructions_per_env_step": per_group * 3, "peak_wave_instructions_per_s": 860e9,
+            "source": "profiles/r02_b_sq_counters.json (3 step groups), profiles/r02_b_ubench_valu_latency.txt"}
+
+
 def build_population(workload, n_envs, rank):
     """Host-side synthetic input, built BEFORE the GPU is initialised (uses a fork pool)."""
     from gym_rem2d_amd import synthetic
@@ -364,6 +380,10 @@ def main():
                                   else (None, None))
     traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
     err = int(env.errors().max())
+    issue = valu_issue(n_groups) if traffic_src and pipeline == 3 else None
+    if issue:
+        issue["achieved_wave_instructions_per_s"] = issue["wave_instructions_per_env_step"] * args.steps / dt
+        issue["frac"] = issue["achieved_wave_instructions_per_s"] / issue["peak_wave_instructions_per_s"]
 
     if rank == 0:
         total = n_envs * world
@@ -405,9 +425,12 @@ def main():
                          "achieved_wall": bytes_per_step * args.steps / dt / 1e9,
                          "frac_wall": bytes_per_step * args.steps / dt / 1e9 / 8000.0,
                          "valu_tflops_est": valu, "valu_frac_of_157.3": valu / 157.3,
+                         # the roof this path actually runs under: VALU wave-instruction issue (at ~10 of 64 lanes)
+                         "valu_issue": issue,
                          "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d), all of them "
-                                 "charged to the dominant kernel; the path is bound by dependent-instruction latency of "
-                                 "the 180+60 Gauss-Seidel sweeps (FP32 VALU), not by HBM"},
+                                 "charged to the dominant kernel; the path is bound by the per-wavefront issue interval over "
+                                 "the 180+60 Gauss-Seidel sweeps (FP32 VALU; valu_issue.frac of the measured issue "
+                                 "peak), not by HBM"},
         }
         if dt < 0.5:
             out["config"]["note"] = "timed region shorter than 0.5 s: expect a few per cent of run-to-run noise"
