@@ -51,12 +51,14 @@ template <int SETS, int PASSES> struct Vel4Shared {
 };
 
 // one joint: what the 180 iterations read (constants) and write (accumulated impulses).  The inverse inertias come
-// with the velocity records; the limit-only terms of the 3x3 mass matrix (ezx, ezy, ezz and its cofactors) are
-// recomputed where the limit is active -- the same expressions on the same operands, hence the same bits.
+// with the velocity records.  The limit-only terms of the 3x3 mass matrix (third column ezx, ezy; cross(ey, ez)) stay in
+// registers too: some joint of a tile is at its limit in four slots out of five, so the wave recomputed them (19 of the
+// ~110 instructions of a joint slot) in nearly every slot.
 struct JointT {
     V2 rA, rB;
     float mA, mB;
     float exx, eyx, eyy, motorMass, det33, det22;
+    float ezx, ezy, cyzx, cyzy, cyzz;
     float impX, impY, impZ, motorImp, motorSpeed, maxMotorImpulse;
     int key; // jA | jB << 8 | jround << 16 | limitState << 24 | phase << 26 | valid << 31
 };
@@ -101,6 +103,7 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
     const float cyzx = J.eyy * ezz - ezy * ezy;
     const float cyzy = ezy * ezx - J.eyx * ezz;
     const float cyzz = J.eyx * ezy - J.eyy * ezx;
+    J.ezx = ezx; J.ezy = ezy; J.cyzx = cyzx; J.cyzy = cyzy; J.cyzz = cyzz;
     J.det33 = J.exx * cyzx + J.eyx * cyzy + ezx * cyzz;
     if (J.det33 != 0.0f) J.det33 = 1.0f / J.det33;
     J.det22 = J.exx * J.eyy - J.eyx * J.eyx;
@@ -126,12 +129,8 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
     }
     if (limitState != LIM_INACTIVE) {
         // ex = (exx, eyx, ezx), ey = (eyx, eyy, ezy), ez = (ezx, ezy, ezz) of m_mass; cyz = cross(ey, ez)
-        const float ezx = -j.rA.y * iA - j.rB.y * iB;
-        const float ezy = j.rA.x * iA + j.rB.x * iB;
-        const float ezz = iA + iB;
-        const float cyzx = j.eyy * ezz - ezy * ezy;
-        const float cyzy = ezy * ezx - j.eyx * ezz;
-        const float cyzz = j.eyx * ezy - j.eyy * ezx;
+        const float ezx = j.ezx, ezy = j.ezy, ezz = iA + iB;
+        const float cyzx = j.cyzx, cyzy = j.cyzy, cyzz = j.cyzz;
         V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
         float Cdot2 = wB - wA;
         float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
