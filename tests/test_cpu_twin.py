@@ -121,9 +121,12 @@ def test_twin_call_order_and_argument_errors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [0, 1])
-def test_same_call_sequence_same_arena(gpu, flags):
-    """The drop-in statement at the boundary: one sequence of ABI calls, two libraries, equal state fields."""
+@pytest.mark.parametrize("flags,steps", [(0, (0, 1, 30, 120)), (1, (0, 1, 30, 120)), (1 | 2, (40, 160)), (1 | 4, (40, 160)),
+                                         (1 | 8, (60, 90, 150, 100))])
+def test_same_call_sequence_same_arena(gpu, flags, steps):
+    """The drop-in statement at the boundary: one sequence of ABI calls, two libraries, equal state fields -- discrete
+    and continuous physics, both sleep variants, and REM2D_FLAG_SKIP_FROZEN (8: wavefronts whose creatures all have a
+    final fitness stop being stepped, in both libraries at the same step)."""
     from gym_rem2d_amd import make_terrain
     from gym_rem2d_amd.world import BatchedWorld
     T = _twin()
@@ -148,7 +151,7 @@ def test_same_call_sequence_same_arena(gpu, flags):
                     "jmotorspeed", "jlimit", "camp", "cphase", "cfreq", "coffset", "cistate", "parent"]
     env_fields = ["wod", "fitness", "reward", "done", "everdone", "frozen", "steps", "invdt0", "positers", "toievents"]
     total = 0
-    for n in (0, 1, 30, 120):
+    for n in steps:
         if n:
             g.step(n)
             c.step(n)
@@ -173,5 +176,42 @@ def test_same_call_sequence_same_arena(gpu, flags):
                 for name in (key, nn, tt):
                     assert np.array_equal(g.view(name).cpu().numpy()[k][mj], c.view(name)[k][mj]), (name, total)
     assert int(g.view("err").max()) == 0
+    if flags & 8:
+        assert 0 < int(c.view("frozen").sum()) and int(c.view("steps").min()) < total  # some wavefronts did stop early
+    g.close()
+    c.close()
+
+
+@pytest.mark.gpu
+def test_step_ex_and_outputs_through_both_libraries(gpu):
+    """rem2d_world_step_ex with other iteration counts / dt, and rem2d_world_set_outputs (population-order reward/done)."""
+    import torch
+    from gym_rem2d_amd import make_terrain
+    from gym_rem2d_amd.world import BatchedWorld
+    T = _twin()
+    morph = _population()
+    terrain = make_terrain(4, flat=True)
+    g = BatchedWorld(morph.n_envs, morph.lanes, flags=1)
+    c = T.CpuWorld(morph.n_envs, morph.lanes, 1)
+    perm = np.random.RandomState(3).permutation(morph.n_envs).astype(np.int32)
+    g_out = (torch.zeros(morph.n_envs, device="cuda"), torch.zeros(morph.n_envs, dtype=torch.bool, device="cuda"),
+             torch.from_numpy(perm).cuda())
+    c_out = (np.zeros(morph.n_envs, np.float32), np.zeros(morph.n_envs, np.uint8), perm.copy())
+    for w, o in ((g, g_out), (c, c_out)):
+        w.set_terrain(terrain)
+        w.reset(morph)
+        w.set_outputs(*o)
+        w.step_ex(25, 1.0 / 50.0, 180, 60)
+        w.step_ex(10, 1.0 / 60.0, 8, 3)
+        w.step_ex(15, 1.0 / 50.0, 30, 0)
+        w.step(5)
+    active = c.view("shape") != 0
+    for name in ("px", "py", "ang", "vx", "vy", "w", "sleept", "awake", "jimpx", "jimpy", "jimpz", "jmotorimp"):
+        assert np.array_equal(g.view(name).cpu().numpy()[active], c.view(name)[active]), name
+    for name in ("wod", "fitness", "reward", "done", "steps", "invdt0", "positers", "toievents"):
+        assert np.array_equal(g.view(name).cpu().numpy(), c.view(name)), name
+    assert np.array_equal(g_out[0].cpu().numpy(), c_out[0])
+    assert np.array_equal(g_out[1].cpu().numpy().astype(np.uint8), c_out[1])
+    assert np.array_equal(c_out[0][perm], c.view("reward"))
     g.close()
     c.close()
