@@ -125,6 +125,9 @@ def lib():
     L.rem2d_world_set_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.rem2d_world_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rem2d_plan_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rem2d_plan_tiles_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p]
+    L.rem2d_world_set_tile_shape.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
     L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
@@ -141,21 +144,22 @@ def lib():
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 3:
+    if L.rem2d_abi_version() != 4:
         raise Rem2dError("librem2d.so ABI version mismatch")
     _lib = L
     return L
 
 
-def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0):
-    """Tile plan of the velocity kernel for one morphology batch (rem2d_plan_tiles): int32 tile starts [n_tiles + 1]."""
+def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_shape=-1):
+    """Tile plan of the velocity kernel for one morphology batch (rem2d_plan_tiles_shape): int32 tile starts
+    [n_tiles + 1].  tile_shape: 0 / 1 / 3, or -1 for the process default."""
     import numpy as np
     parent = np.ascontiguousarray(parent, dtype=np.int32)
     jround = np.ascontiguousarray(jround, dtype=np.int32)
     out = np.zeros(int(n_padded) + 1, dtype=np.int32)
     n = C.c_int32()
-    check(lib().rem2d_plan_tiles(parent.ctypes.data, jround.ctypes.data, int(n_envs), int(lanes), int(n_padded),
-                                 int(max_creatures), out.ctypes.data, C.byref(n)))
+    check(lib().rem2d_plan_tiles_shape(parent.ctypes.data, jround.ctypes.data, int(n_envs), int(lanes), int(n_padded),
+                                       int(max_creatures), int(tile_shape), out.ctypes.data, C.byref(n)))
     return out[:n.value + 1].copy()
 
 

@@ -109,12 +109,14 @@ struct rem2d_world {
     int evUsed;
     // second bracket: all kernels of one env-step (pre .. toi_heavy) of the tile pipeline
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evPoolStep;
+    int tileShape; // REM2D_TILE_SHAPE id of rem2d_vel4_kernel for this world's tiles
     int evUsedStep;
     double accumMsStep;
     int64_t launchesStep;
 };
 
 // Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
+//   (the process-wide default of a world's shape; rem2d_world_set_tile_shape overrides it per world)
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
 //   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
 struct TileShape { int sets, passes, csets; };
@@ -122,9 +124,9 @@ static int tile_shape_id() {
     static const int id = getenv("REM2D_TILE_SHAPE") ? atoi(getenv("REM2D_TILE_SHAPE")) : 3;
     return (id == 0 || id == 1) ? id : 3;
 }
-static TileShape tile_shape() {
+static TileShape tile_shape(int id) {
     static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}}; // [2] unused
-    return shapes[tile_shape_id()];
+    return shapes[(id == 0 || id == 1) ? id : 3];
 }
 
 extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
@@ -205,7 +207,8 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
     {
         // (with one joint set per lane a tile holds at most 64 joints: 64 / lanes creatures)
-        const TileShape shp = tile_shape();
+        w->tileShape = tile_shape_id();
+        const TileShape shp = tile_shape(w->tileShape);
         // 4 sets = one phase per set: 128 / lanes creatures; fewer sets share phases, so keep to 64 joints in all
         int per = (shp.sets >= V4_PHASES ? 128 : 64) / cfg->lanes;
         if (per * cfg->lanes > shp.passes * WAVE) per = shp.passes * WAVE / cfg->lanes;
@@ -236,6 +239,22 @@ extern "C" int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_
     return REM2D_OK;
 }
 
+extern "C" int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape_sel) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if (tile_shape_sel != 0 && tile_shape_sel != 1 && tile_shape_sel != 3) return fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");
+    if (w->tileShape == tile_shape_sel) return REM2D_OK;
+    w->tileShape = tile_shape_sel;
+    // the tile table in place may not fit the new shape: back to the default plan, valid for every morphology
+    const TileShape shp = tile_shape(w->tileShape);
+    int per = (shp.sets >= V4_PHASES ? 128 : 64) / w->cfg.lanes;
+    if (per * w->cfg.lanes > shp.passes * WAVE) per = shp.passes * WAVE / w->cfg.lanes;
+    if (per < 1) per = 1;
+    std::vector<int32_t> ts;
+    for (int c = 0; c < w->L.Np; c += per) ts.push_back(c);
+    ts.push_back(w->L.Np);
+    return rem2d_world_set_tiles(w, ts.data(), (int32_t)ts.size() - 1);
+}
+
 extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_tiles) {
     if (!w || !tile_start || n_tiles <= 0) return fail(REM2D_E_INVALID, "tiles: NULL table or no tiles");
     if (tile_start[0] != 0 || tile_start[n_tiles] < w->cfg.n_envs || tile_start[n_tiles] > w->L.Np)
@@ -243,7 +262,7 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
     for (int t = 0; t < n_tiles; ++t) {
         const long long c = (long long)tile_start[t + 1] - tile_start[t];
         if (c <= 0) return fail(REM2D_E_INVALID, "tile starts must be strictly increasing");
-        if (c * w->cfg.lanes > tile_shape().passes * WAVE) return fail(REM2D_E_INVALID, "a tile holds too many lanes for the tile shape in use");
+        if (c * w->cfg.lanes > tile_shape(w->tileShape).passes * WAVE) return fail(REM2D_E_INVALID, "a tile holds too many lanes for the tile shape in use");
     }
     HIP_TRY(hipSetDevice(w->cfg.device));
     int *dev = nullptr;
@@ -262,8 +281,15 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
 
 extern "C" int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                                 int32_t max_creatures, int32_t *tile_start_out, int32_t *n_tiles_out) {
+    return rem2d_plan_tiles_shape(parent, jround, n_envs, lanes, n_padded, max_creatures, -1, tile_start_out, n_tiles_out);
+}
+extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes,
+                                      int32_t n_padded, int32_t max_creatures, int32_t tile_shape_sel, int32_t *tile_start_out,
+                                      int32_t *n_tiles_out) {
     if (!parent || !jround || !tile_start_out || !n_tiles_out) return fail(REM2D_E_INVALID, "plan_tiles: NULL argument");
-    const TileShape sh = tile_shape();
+    if (tile_shape_sel != -1 && tile_shape_sel != 0 && tile_shape_sel != 1 && tile_shape_sel != 3)
+        return fail(REM2D_E_INVALID, "plan_tiles: tile shape must be 0, 1, 3 or -1 (process default)");
+    const TileShape sh = tile_shape(tile_shape_sel < 0 ? tile_shape_id() : tile_shape_sel);
     const int maxLanes = sh.passes * WAVE;
     if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
     if (max_creatures <= 0) {
@@ -550,6 +576,13 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     }
     B.n = VB.n = n_worlds;
     rem2d_world *w0 = ws[0];
+    // worlds planned for different tile shapes in one grid: the largest shape runs the smaller ones' tiles as well
+    // (a tile within 64 joints fits any shape; one within 64 joints per phase pair fits the four-set shape)
+    int launchShape = 3;
+    for (int i = 0; i < n_worlds; ++i) {
+        const int id = ws[i]->tileShape;
+        if (id == 0 || (id == 1 && launchShape == 3)) launchShape = id;
+    }
     const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     StepArgs A;
     A.nSteps = 1;
@@ -572,7 +605,7 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         // also count the dispatch gaps, 50-100 us when three step groups share the command processor)
         const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
         hipEvent_t e0 = timed ? w0->evPool[w0->evUsed].first : nullptr, e1 = timed ? w0->evPool[w0->evUsed].second : nullptr;
-        switch (tile_shape_id()) {
+        switch (launchShape) {
         case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
         default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;

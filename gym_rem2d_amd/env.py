@@ -52,6 +52,7 @@ class WallOfDeath:
 
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
+    BIG_POPULATION = 100000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
@@ -69,6 +70,11 @@ class BatchedModular2D:
         # REM2D_MERGED_LAUNCH=0: step every lane bucket on its own stream instead of one merged grid
         self.merged_launch = os.environ.get("REM2D_MERGED_LAUNCH", "1") != "0"
         self.step_groups = int(os.environ.get("REM2D_STEP_GROUPS", "0"))  # 0 = automatic
+        # launch shape of the velocity kernel (rem2d_world_set_tile_shape): None = automatic, unless REM2D_TILE_SHAPE
+        # fixes the process default.  Up to ~100 000 creatures a step is bound by its chain of stragglers and the
+        # 64-lane tiles (4 wavefronts per SIMD) win; beyond that the chip's instruction issue saturates and the 256-lane
+        # tiles (2.4x fewer wave-instructions) do: 51.7 vs 46.5 M env-steps/s at 131 072 creatures.
+        self.tile_shape = None
         self.groups, self.group_streams = [], []
 
     def seed(self, seed=None):
@@ -132,6 +138,9 @@ class BatchedModular2D:
             groups = 1
             if (self.flags & _lib.FLAG_CONTINUOUS) and big:
                 groups = 3 if n_envs >= 49152 else (2 if n_envs >= 32768 else 1)
+        shape = self.tile_shape
+        if shape is None and "REM2D_TILE_SHAPE" not in os.environ:
+            shape = 0 if n_envs >= self.BIG_POPULATION else 3
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
@@ -145,7 +154,7 @@ class BatchedModular2D:
                 part = morph if (lo == 0 and hi == morph.n_envs) else morph.take(np.arange(lo, hi))
                 w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device)
                 w.set_terrain(self._terrain())
-                w.reset(part)
+                w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
                 self.worlds.append((w, torch.as_tensor(idx[lo:hi], dtype=torch.long, device=w.device)))
                 # fallback path (REM2D_MERGED_LAUNCH=0): one HIP stream per world

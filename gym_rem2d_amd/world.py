@@ -36,6 +36,7 @@ class BatchedWorld:
         self._views = {}
         self._morph_dev = None
         self.terrain = None
+        self.tile_shape = -1  # -1: the library's process default
 
     def close(self):
         if getattr(self, "h", None):
@@ -61,7 +62,9 @@ class BatchedWorld:
         self.terrain = terrain
 
     # ---- reset: upload the morphology and rebuild every world ----
-    def reset(self, morph: Morphology):
+    def reset(self, morph: Morphology, tile_shape=None):
+        """tile_shape: launch shape of the velocity kernel for this world (0 / 1 / 3, include/rem2d.h
+        rem2d_world_set_tile_shape); None keeps the world's current one (the process default REM2D_TILE_SHAPE or 3)."""
         if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
             raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %
                              (morph.n_envs, morph.lanes, self.n_envs, self.lanes))
@@ -75,8 +78,11 @@ class BatchedWorld:
         _lib.check(_lib.lib().rem2d_world_reset(self.h, C.byref(m), self._stream()))
         # work partition of the velocity kernel: consecutive creatures packed into tiles of <= 256 lanes with <= 64
         # joints per schedule phase (include/rem2d.h, rem2d_world_set_tiles)
+        if tile_shape is not None:
+            _lib.check(_lib.lib().rem2d_world_set_tile_shape(self.h, int(tile_shape)))
+            self.tile_shape = int(tile_shape)
         self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
-                                     self.n_envs_padded)
+                                     self.n_envs_padded, tile_shape=self.tile_shape)
         _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def set_outputs(self, reward, done, index):

@@ -70,6 +70,7 @@ def lib():
         L.rem2d_cpu_world_reset.argtypes = [C.c_void_p, C.POINTER(Morph), C.c_void_p]
         L.rem2d_cpu_world_set_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rem2d_cpu_world_set_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.rem2d_cpu_world_set_tile_shape.argtypes = [C.c_void_p, C.c_int32]
         L.rem2d_cpu_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.rem2d_cpu_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
         L.rem2d_cpu_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]

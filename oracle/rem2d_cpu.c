@@ -158,6 +158,11 @@ int rem2d_cpu_world_set_tiles(rem2d_cpu_world *w, const int32_t *tile_start, int
     (void)tile_start; (void)n_tiles;
     return w ? REM2D_OK : c_fail(REM2D_E_INVALID, "world is NULL"); /* a launch shape: nothing to do on the CPU */
 }
+int rem2d_cpu_world_set_tile_shape(rem2d_cpu_world *w, int32_t tile_shape) {
+    if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
+    if (tile_shape != 0 && tile_shape != 1 && tile_shape != 3) return c_fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");
+    return REM2D_OK; /* a launch shape: nothing to do on the CPU */
+}
 int rem2d_cpu_world_field(const rem2d_cpu_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
     if (!w || field < 0 || field >= REM2D_F_COUNT) return c_fail(REM2D_E_INVALID, "bad field id");
     int dt = 0;

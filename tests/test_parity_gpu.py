@@ -449,3 +449,38 @@ def test_full_size_config5_generation_share(gpu, oracle, rough_terrain):
     ok = ~bad[sample]
     assert ok.mean() > 0.99                                          # overflow (flagged, not silent) is rare
     assert np.array_equal(fit[sample][ok], ref[sample][ok])
+
+
+def test_tile_shape_per_world_and_mixed_in_one_launch(gpu, oracle, rough_terrain):
+    """rem2d_world_set_tile_shape: the launch shape of the velocity kernel is a property of the world (the env picks
+    the 256-lane tiles for populations beyond ~100 000 creatures).  The three shapes give the oracle's bits, also when
+    worlds planned for different shapes share one merged launch (rem2d_worlds_step)."""
+    import ctypes as C
+    from gym_rem2d_amd import _lib
+    pops = _populations()
+    morphs = [pops["lsystem_k32"], pops["chain8_top"], pops["direct"]]
+    T = 90
+    refs = [oracle.batch_run(oracle_terrain(oracle, rough_terrain), m.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+            for m in morphs]
+    for shapes in ((0, 0, 0), (1, 1, 1), (3, 3, 3), (0, 3, 1), (3, 1, 0)):
+        ws = []
+        for m, sh in zip(morphs, shapes):
+            if m.lanes > (256, 128, 0, 64)[sh]:
+                sh = 0
+            w = gpu(m.n_envs, m.lanes, flags=_lib.FLAG_CONTINUOUS)
+            w.set_terrain(rough_terrain)
+            w.reset(m, tile_shape=sh)
+            assert w.tile_shape == sh
+            ws.append(w)
+        arr = (C.c_void_p * len(ws))(*[w.h for w in ws])
+        for n in (1, 29, 60):
+            _lib.check(_lib.lib().rem2d_worlds_step(arr, len(ws), n, ws[0]._stream()))
+        for w, ref in zip(ws, refs):
+            assert np.array_equal(w.bodies(), ref["bodies"]), shapes
+            assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+            assert int(w.view("err").max()) == 0
+            w.close()
+    w = gpu(morphs[0].n_envs, morphs[0].lanes)
+    with pytest.raises(_lib.Rem2dError, match="tile shape"):
+        _lib.check(_lib.lib().rem2d_world_set_tile_shape(w.h, 2))
+    w.close()
