@@ -35,7 +35,7 @@
 #define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
 #define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
-struct Vel4Args { int velIters; float dt; int dbg; /* diagnostic builds (-DREM2D_V4_PROBES) only: 1 skip contact sub-slots, 2 skip joint slots, 8 s_memtime split */ };
+struct Vel4Args { int velIters; float dt; int dbg; /* diagnostic builds (-DREM2D_V4_PROBES) only: 1 skip contact sub-slots, 2 skip joint slots, 8 s_memtime split, 16 start / end time of every wavefront */ };
 #ifdef REM2D_V4_PROBES
 #define V4_DBG(A) ((A).dbg)
 #else
@@ -230,6 +230,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const unsigned Lp = S.Lp;
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
+    const unsigned long long rEntry = (V4_DBG(A) & 16) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
     const unsigned tb0 = (unsigned)c0 * (unsigned)K;
     const int iters = A.velIters;
     const float h = A.dt, mu = friction;
@@ -521,6 +522,11 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     if (err && lane == 0) {
         const unsigned env = (unsigned)c0;
         atomicOr(&EI(E_ERR), err);
+    }
+    if ((V4_DBG(A) & 16) && lane == 0 && c1 - c0 >= 2) { // diagnostic: when did this wavefront start and end (tools/dispatch_probe.py)
+        unsigned env = (unsigned)c0;
+        EI(E_TOIEVENTS) = (int)(rEntry & 0x7fffffff);
+        env = (unsigned)c0 + 1; EI(E_TOIEVENTS) = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
     }
 }
 
