@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--step-groups", type=int, default=None,
                     help="independent halves/thirds of the population stepped on separate streams (default: automatic)")
     ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2, 3],
-                    help="3 = tile pipeline pre / rem2d_vel4_kernel / post (the library's default), 0 = fused rem2d_step_kernel")
+                    help="3 = tile pipeline pre / rem2d_vel4_kernel / post (the library's default), 0 = fused rem2d_step_multi_kernel")
     ap.add_argument("--discrete", action="store_true",
                     help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
     args = ap.parse_args()
@@ -367,7 +367,7 @@ def main():
         ms, launches, ms_step, n_step = ms + a, launches + b, ms_step + c, n_step + d
     merged = len(env.worlds) > 1 and env.merged_launch
     n_groups = max(1, len(env.groups))
-    kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel" if merged else "rem2d_step_kernel<%d>" % morphs[0].lanes,
+    kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel",
              1: "rem2d_vel_kernel", 2: "rem2d_vel3_kernel"}[pipeline]
     bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
     flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))

@@ -622,6 +622,44 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     return REM2D_OK;
 }
 
+// The fused formulation (REM2D_PIPELINE=0; round 1's body-per-lane step kernel + the TOI kernels) for one or several
+// worlds in one grid per kernel: n_steps env-steps per launch in discrete mode, one per launch when the TOI kernels follow.
+static int step_fused(rem2d_world *const *ws, int n_worlds, int n_steps, float dt, int vel_iters, int pos_iters, hipStream_t st) {
+    Batch B;
+    memset(&B, 0, sizeof(B));
+    unsigned blocks = 0;
+    for (int i = 0; i < n_worlds; ++i) {
+        rem2d_world *w = ws[i];
+        B.S[i] = w->S;
+        B.T[i] = w->T;
+        B.lanes[i] = w->cfg.lanes;
+        blocks += (unsigned)w->L.Lp / WAVE;
+        B.blockEnd[i] = blocks;
+    }
+    B.n = n_worlds;
+    rem2d_world *w0 = ws[0];
+    const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
+    StepArgs A;
+    A.nSteps = continuous ? 1 : n_steps;
+    A.dt = dt;
+    A.velIters = vel_iters;
+    A.posIters = pos_iters;
+    A.defer = continuous ? 1 : 0;
+    dim3 grid(blocks), block(WAVE);
+    const int launches = continuous ? n_steps : 1;
+    for (int l = 0; l < launches; ++l) {
+        const bool timed = timing_begin(w0, st);
+        hipLaunchKernelGGL(rem2d_step_multi_kernel, grid, block, 0, st, B, A);
+        if (timed) timing_end(w0, st);
+        if (continuous) {
+            hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
+            hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
+
 extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                                    void *stream) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
@@ -630,40 +668,7 @@ extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, in
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
     if (pipeline_mode() == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
-    // ---- fused kernel: n_steps env-steps per launch in discrete mode, one per launch when the TOI kernels follow ----
-    const bool continuous = (w->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    StepArgs A;
-    A.nSteps = continuous ? 1 : n_steps;
-    A.dt = dt;
-    A.velIters = vel_iters;
-    A.posIters = pos_iters;
-    A.defer = continuous ? 1 : 0;
-    dim3 grid((unsigned)w->L.Lp / WAVE), block(WAVE);
-    hipStream_t st = (hipStream_t)stream;
-    const int launches = continuous ? n_steps : 1;
-#define LAUNCH_K(NAME, KK) hipLaunchKernelGGL((NAME<KK>), grid, block, 0, st, w->S, w->T, A)
-#define LAUNCH_BY_LANES(NAME)                  \
-    switch (w->cfg.lanes) {                    \
-    case 2: LAUNCH_K(NAME, 2); break;          \
-    case 4: LAUNCH_K(NAME, 4); break;          \
-    case 8: LAUNCH_K(NAME, 8); break;          \
-    case 16: LAUNCH_K(NAME, 16); break;        \
-    case 32: LAUNCH_K(NAME, 32); break;        \
-    default: LAUNCH_K(NAME, 64); break;        \
-    }
-    for (int l = 0; l < launches; ++l) {
-        const bool timed = timing_begin(w, st); // the dominant kernel only (bench.py's roofline leg)
-        LAUNCH_BY_LANES(rem2d_step_kernel);
-        if (timed) timing_end(w, st);
-        if (continuous) {
-            LAUNCH_BY_LANES(rem2d_toi_scan_kernel);
-            LAUNCH_BY_LANES(rem2d_toi_heavy_kernel);
-        }
-    }
-#undef LAUNCH_BY_LANES
-#undef LAUNCH_K
-    HIP_TRY(hipGetLastError());
-    return REM2D_OK;
+    return step_fused(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
 }
 extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                                     int32_t pos_iters, void *stream) {
@@ -684,39 +689,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     rem2d_world *w0 = ws[0];
     HIP_TRY(hipSetDevice(w0->cfg.device));
     if (pipeline_mode() == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
-    Batch B;
-    memset(&B, 0, sizeof(B));
-    unsigned blocks = 0;
-    for (int i = 0; i < n_worlds; ++i) {
-        rem2d_world *w = ws[i];
-        B.S[i] = w->S;
-        B.T[i] = w->T;
-        B.lanes[i] = w->cfg.lanes;
-        blocks += (unsigned)w->L.Lp / WAVE;
-        B.blockEnd[i] = blocks;
-    }
-    B.n = n_worlds;
-    const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    StepArgs A;
-    A.nSteps = continuous ? 1 : n_steps;
-    A.dt = dt;
-    A.velIters = vel_iters;
-    A.posIters = pos_iters;
-    A.defer = continuous ? 1 : 0;
-    dim3 grid(blocks), block(WAVE);
-    hipStream_t st = (hipStream_t)stream;
-    const int launches = continuous ? n_steps : 1;
-    for (int l = 0; l < launches; ++l) {
-        const bool timed = timing_begin(w0, st);
-        hipLaunchKernelGGL(rem2d_step_multi_kernel, grid, block, 0, st, B, A);
-        if (timed) timing_end(w0, st);
-        if (continuous) {
-            hipLaunchKernelGGL(rem2d_toi_scan_multi_kernel, grid, block, 0, st, B, A);
-            hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
-        }
-    }
-    HIP_TRY(hipGetLastError());
-    return REM2D_OK;
+    return step_fused(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
 }
 extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, void *stream) {
     return rem2d_worlds_step_ex(ws, n_worlds, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream);

@@ -1,4 +1,4 @@
-// rem2d_kernels.h -- rem2d_step_kernel, rem2d_toi_kernel, rem2d_reset_kernel.
+// rem2d_kernels.h -- rem2d_step_multi_kernel, rem2d_toi_kernel, rem2d_reset_kernel.
 // Part of the single translation unit rem2d.hip (see its header comment); not a stand-alone header.
 #ifndef REM2D_KERNELS_H
 #define REM2D_KERNELS_H
@@ -474,11 +474,6 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_step_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ PosShared psh;
-    step_body<K>(S, T, A, blockIdx.x, psh);
-}
 
 // ---- several worlds (lane buckets of one population) in ONE launch ----
 // Kernels of different worlds launched on different streams barely overlap: a big bucket's grid owns every
@@ -519,13 +514,13 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_multi_kernel(Batch B, Step
 // kernel when REM2D_FLAG_CONTINUOUS is set; kept out of the step kernel so that the branchy GJK /
 // root-finder code does not share a register allocation with the velocity loop.
 //
-//   rem2d_toi_scan_kernel   lane = body.  Invalidates last step's TOI flags and applies the two exact
+//   rem2d_toi_scan_multi_kernel   lane = body.  Invalidates last step's TOI flags and applies the two exact
 //                           early-outs (toi_far_apart) to every pair.  A body all of whose pairs are far
 //                           apart has alpha = 1 everywhere: SolveTOI leaves it untouched.  The others
 //                           (a few per cent: bodies that are landing or sliding into an edge) are appended
 //                           to a work list.  Light (no GJK), so it runs at high occupancy over its
 //                           memory latency.
-//   rem2d_toi_heavy_kernel  lane = work-list entry: the full solve_toi_lane for that body, i.e. dense
+//   rem2d_toi_heavy_multi_kernel  lane = work-list entry: the full solve_toi_lane for that body, i.e. dense
 //                           wavefronts of bodies that really need b2TimeOfImpact / TOI sub-steps instead
 //                           of one such lane per wavefront.  Bodies are independent (terrain sweeps are
 //                           time-transparent), so the list order does not matter.
@@ -597,15 +592,6 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     if ((gl & (K - 1)) == 0) env_bookkeeping(S, env, 0, B.px);
 }
 
-template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_toi_scan_kernel(State S, Terrain T, StepArgs A) {
-    toi_scan_body<K>(S, T, A, blockIdx.x);
-}
-template <int K>
-__global__ __launch_bounds__(WAVE, 2) void rem2d_toi_heavy_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ ToiShared ts;
-    toi_heavy_body<K>(S, T, A, blockIdx.x, ts);
-}
 __global__ __launch_bounds__(WAVE) void rem2d_toi_scan_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);

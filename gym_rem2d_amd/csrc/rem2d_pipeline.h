@@ -1,7 +1,7 @@
-// rem2d_pipeline.h -- the two body-per-lane ends of the tile pipeline: rem2d_pre_kernel -> (rem2d_vel4_kernel,
-// rem2d_vel4.h) -> rem2d_post_kernel.  Part of the single translation unit rem2d.hip; not a stand-alone header.
+// rem2d_pipeline.h -- the two body-per-lane ends of the tile pipeline: rem2d_pre_multi_kernel -> (rem2d_vel4_kernel,
+// rem2d_vel4.h) -> rem2d_post_multi_kernel.  Part of the single translation unit rem2d.hip; not a stand-alone header.
 //
-// Same arithmetic as rem2d_step_kernel, cut at the two ends of the velocity phase of b2Island::Solve so that the 180
+// Same arithmetic as rem2d_step_multi_kernel, cut at the two ends of the velocity phase of b2Island::Solve so that the 180
 // velocity iterations run in a kernel of their own whose lanes are constraints:
 //
 //   pre  (lane = body, workgroup = wave64): controller / PID, Collide, velocity integration, contact and
@@ -184,10 +184,6 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_pre_kernel(State S, Terrain T, StepArgs A) {
-    pre_body<K>(S, T, A, blockIdx.x);
-}
 __global__ __launch_bounds__(WAVE) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
@@ -336,11 +332,6 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     else if (A.defer == 2) toi_scan_lane(S, T, A.dt, gl, env, sub, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
 }
 
-template <int K>
-__global__ __launch_bounds__(WAVE) void rem2d_post_kernel(State S, Terrain T, StepArgs A) {
-    __shared__ PosShared psh;
-    post_body<K>(S, T, A, blockIdx.x, psh);
-}
 __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArgs A) {
     __shared__ PosShared psh;
     unsigned block = blockIdx.x;

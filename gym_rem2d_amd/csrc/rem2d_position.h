@@ -1,5 +1,5 @@
-// rem2d_position.h -- software-pipelined position iterations of b2Island::Solve (shared by rem2d_step_kernel
-// and rem2d_post_kernel).  Part of the single translation unit rem2d.hip; not a stand-alone header.
+// rem2d_position.h -- software-pipelined position iterations of b2Island::Solve (shared by rem2d_step_multi_kernel
+// and rem2d_post_multi_kernel).  Part of the single translation unit rem2d.hip; not a stand-alone header.
 #ifndef REM2D_POSITION_H
 #define REM2D_POSITION_H
 

@@ -2,7 +2,7 @@
 // Part of the single translation unit rem2d.hip; not a stand-alone header.
 //
 // b2Island::Solve's 180 velocity iterations are one long dependent chain per creature; what a wavefront can
-// change is how many creatures ride on one chain.  rem2d_step_kernel keeps one body per lane: a joint slot runs
+// change is how many creatures ride on one chain.  rem2d_step_multi_kernel keeps one body per lane: a joint slot runs
 // with 1/period of its lanes and a contact slot with ~5 % of them, so the population needs ~4 rounds of
 // wavefronts, each paying the whole chain.  Here a wavefront owns a TILE: a run of consecutive creatures with
 // at most 256 bodies whose joints number at most 64 in every phase of the modulo schedule (the host cuts the
@@ -19,7 +19,7 @@
 //     (lds_sync = s_waitcnt, no s_barrier).
 // The whole 65 536-creature population is ~3000 tiles.  Arithmetic and ordering are those of the other forms
 // (compiler.pipeline_schedule proves that any two operations sharing a body keep Box2D's sequential order for
-// any period >= the creature's own), so the result is bit-identical to rem2d_step_kernel and to the oracle.
+// any period >= the creature's own), so the result is bit-identical to rem2d_step_multi_kernel and to the oracle.
 #ifndef REM2D_VEL4_H
 #define REM2D_VEL4_H
 
@@ -91,7 +91,7 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
     J.key = jA | (child << 8) | (jround << 16) | (limitState << 24) | ((jround % P) << 26) | (int)0x80000000;
     const float mA = J.mA, mB = J.mB;
     const V2 rA = J.rA, rB = J.rB;
-    // effective-mass terms of b2RevoluteJoint::InitVelocityConstraints (same expressions as rem2d_step_kernel)
+    // effective-mass terms of b2RevoluteJoint::InitVelocityConstraints (same expressions as rem2d_step_multi_kernel)
     J.exx = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
     J.eyx = -rA.y * rA.x * iA - rB.y * rB.x * iB;
     const float ezx = -rA.y * iA - rB.y * iB;
@@ -111,7 +111,7 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
 }
 
 // b2RevoluteJoint::SolveVelocityConstraints (motor, then limit 3x3 / point 2x2) on the mailbox records of the
-// joint's two bodies; same expression sequence as the joint slot of rem2d_step_kernel
+// joint's two bodies; same expression sequence as the joint slot of rem2d_step_multi_kernel
 template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
     const int a = V4_JA(j.key), b = V4_JB(j.key), limitState = V4_LIMIT(j.key);
     V4Vel ra = sh.vel[a], rb = sh.vel[b];
