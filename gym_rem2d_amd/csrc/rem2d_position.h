@@ -10,8 +10,8 @@
 // tolerance: break }.  The joints of one iteration form a chain of `rounds` dependent steps, but joint k
 // of iteration n+1 only has to wait for the operations of iteration n that share one of its two bodies,
 // so iteration n+1 can start `period` ticks after iteration n (same modulo schedule as the velocity
-// iterations; one tick = a contact slot, then a joint slot; body b's contacts fire in the tick of its
-// first joint).  The catch is the exit test: whether iteration n was the last one is only known when its
+// iterations; one tick = a contact slot, then a joint slot; body b's contacts fire in a tick of its window
+// between its last joint of the previous iteration and its first joint of this one).  The catch is the exit test: whether iteration n was the last one is only known when its
 // last joint has run, by which time early joints of iterations n+1.. have already moved bodies.  Every
 // body therefore snapshots its position after its last operation of each iteration into a ring in LDS;
 // when iteration n passes the test the creature's bodies are rolled back to snapshot n -- exactly the
@@ -26,7 +26,7 @@ struct PosShared {
 };
 // manifold geometry as the position solver reads it (b2PositionSolverManifold): type | count << 8, local normal,
 // local point, two manifold points
-#define POS_KR 2
+#define POS_KR 3
 struct PosManifold { int tc; V2 ln, lp, p0, p1; };
 DEV void pos_manifold_load(const State &S, unsigned gl, int t, PosManifold &m) {
     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
@@ -116,7 +116,27 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     const bool touching = active && nTouch > 0;
     const bool hasOps = active && (anyJoint || nTouch > 0);
     const bool run = posIters > 0;
-    int nextC = (run && touching) ? (anyJoint ? sh.firstR[lane] : 0) : 0x7fffffff, leftC = posIters, itC = 0;
+    // Contact slot of body b in iteration n: any tick after its last joint of iteration n - 1 and not after its first
+    // joint of iteration n (the contact section of a tick runs before its joint section), i.e. offC + n P with offC in
+    // [lastR + 1 - P, firstR].  The section costs the wavefront the same whether one lane or all are due, so the bodies
+    // are steered to one common phase: the one inside the window of the most touching bodies of the wavefront; a body
+    // whose window misses it keeps the latest tick (its first joint's).  Iteration 0 has no earlier joints: max(offC, 0).
+    const int hiC = anyJoint ? sh.firstR[lane] : 0, loC = anyJoint ? lastB + 1 - P : 1 - P;
+    int offC = hiC;
+    {
+        const int Pw = wave_max(P);
+        int best = -1, bestPhase = 0;
+        for (int c = 0; c < Pw; ++c) {
+            int d = (c - loC) % P;
+            d = d < 0 ? d + P : d;
+            const int n = __popcll(__ballot(touching && d <= hiC - loC));
+            if (n > best) { best = n; bestPhase = c; }
+        }
+        int d = (bestPhase - loC) % P;
+        d = d < 0 ? d + P : d;
+        if (d <= hiC - loC) offC = loC + d;
+    }
+    int nextC = (run && touching) ? (offC > 0 ? offC : 0) : 0x7fffffff, leftC = posIters, itC = 0;
     int nextJ = (run && hasJoint) ? jround : 0x7fffffff, leftJ = posIters, itJ = 0;
     int nextD = run ? maxR : 0x7fffffff, itD = 0;
     unsigned long long failBits = 0ull;
@@ -143,7 +163,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 sh.snap[r][0][lane] = cx; sh.snap[r][1][lane] = cy; sh.snap[r][2][lane] = ca;
             }
             ++itC;
-            nextC = (--leftC > 0) ? nextC + P : 0x7fffffff;
+            nextC = (--leftC > 0) ? offC + itC * P : 0x7fffffff;
         }
         lds_sync();
         // ---- joint slot: b2RevoluteJoint::SolvePositionConstraints ----
