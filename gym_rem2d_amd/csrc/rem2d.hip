@@ -762,8 +762,8 @@ extern "C" int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int6
     w->launches = 0;
     return REM2D_OK;
 }
-#ifdef REM2D_TOI_STAMPS
-// diagnostic builds only: the TOI kernel's cycle counters (toiWork[0..16)), then zeroed
+#if defined(REM2D_TOI_STAMPS) || defined(REM2D_POS_STAMPS)
+// diagnostic builds only: the TOI kernel's / the position solver's cycle counters (toiWork[0..16)), then zeroed
 extern "C" int rem2d_world_debug_words(rem2d_world *w, int32_t *out16) {
     HIP_TRY(hipSetDevice(w->cfg.device));
     HIP_TRY(hipDeviceSynchronize());

@@ -143,7 +143,18 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     const int lastTick = wave_max(run ? maxR + (posIters - 1) * P : -1);
     sh.mbox[0][lane] = px; sh.mbox[1][lane] = py; sh.mbox[2][lane] = ang;
     lds_sync();
+#ifdef REM2D_POS_STAMPS // diagnostic build (tools/pos_stamps_probe.py): where the cycles of a wavefront's tick loop go
+    unsigned long long pT0 = __builtin_amdgcn_s_memtime(), pTa = pT0, pC = 0, pJ = 0, pV = 0;
+    int pTicks = 0, pCsec = 0, pJsec = 0;
+#define POS_STAMP(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - pTa; pTa = t_; }
+#else
+#define POS_STAMP(acc)
+#endif
     for (int tick = 0; tick <= lastTick; ++tick) {
+#ifdef REM2D_POS_STAMPS
+        pTicks += 1; pCsec += __any(tick == nextC ? 1 : 0) ? 1 : 0; pJsec += __any(tick == nextJ ? 1 : 0) ? 1 : 0;
+        pTa = __builtin_amdgcn_s_memtime();
+#endif
         // ---- contact slot: b2ContactSolver::SolvePositionConstraints for this body's manifolds ----
         if (tick == nextC) {
             float cx = sh.mbox[0][lane], cy = sh.mbox[1][lane], ca = sh.mbox[2][lane];
@@ -166,6 +177,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             nextC = (--leftC > 0) ? offC + itC * P : 0x7fffffff;
         }
         lds_sync();
+        POS_STAMP(pC)
         // ---- joint slot: b2RevoluteJoint::SolvePositionConstraints ----
         if (tick == nextJ) {
             V2 cA = mk(sh.mbox[0][pl], sh.mbox[1][pl]);
@@ -222,9 +234,13 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             nextJ = (--leftJ > 0) ? nextJ + P : 0x7fffffff;
         }
         lds_sync();
+        POS_STAMP(pJ)
         // ---- verdict on the iteration whose last joint has just run (creature-uniform) ----
         const bool due = tick == nextD;
-        const int failed = group_or<K>(due ? (int)((failBits >> (itD & 63)) & 1ull) : 0);
+        // (one ballot and the creature's lane mask instead of a K-lane shuffle reduction in every tick)
+        const unsigned long long failedLanes = __ballot(due && ((failBits >> (itD & 63)) & 1ull) != 0ull);
+        const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
+        const bool failed = (failedLanes & groupLanes) != 0ull;
         if (due) failBits &= ~(1ull << (itD & 63)); // the mask is a ring: at most POS_RING iterations are in flight
         bool restored = false;
         if (due) {
@@ -244,8 +260,17 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             }
         }
         if (__any(restored ? 1 : 0)) lds_sync();
+        POS_STAMP(pV)
         if (__all(nextD == 0x7fffffff ? 1 : 0)) break;
     }
+#ifdef REM2D_POS_STAMPS
+    if (lane == 0 && pTicks >= 40 * P) { // the wavefronts that iterate to the end only
+        const unsigned long long all = __builtin_amdgcn_s_memtime() - pT0;
+        atomicAdd(&S.toiWork[2], (int)(pC >> 6)); atomicAdd(&S.toiWork[3], (int)(pJ >> 6)); atomicAdd(&S.toiWork[4], (int)(pV >> 6));
+        atomicAdd(&S.toiWork[5], (int)(all >> 6)); atomicAdd(&S.toiWork[6], pTicks); atomicAdd(&S.toiWork[7], pCsec);
+        atomicAdd(&S.toiWork[8], pJsec); atomicAdd(&S.toiWork[9], 1); atomicMax(&S.toiWork[10], (int)(all >> 6));
+    }
+#endif
     px = sh.mbox[0][lane]; py = sh.mbox[1][lane]; ang = sh.mbox[2][lane];
 }
 
