@@ -1867,7 +1867,8 @@ static void body_sync_fixtures(o_world *w, int bi) {
 /* Diagnostic build only (tools/probe_fixed_point.py): at which velocity iteration does a sweep stop changing any
  * bit of the solver state?  From there on every further sweep is a no-op. */
 static int g_probe_hist[512];
-static int g_probe_toi[5][256]; /* [period][sweep at which the cycle was first seen]; [0][255] = none within the budget */
+#define PROBE_TOI_P 64
+static int g_probe_toi[PROBE_TOI_P + 1][256]; /* [period][sweep at which the cycle was first seen]; [0][255] = none within the budget */
 static _Thread_local f32 t_probe[2][8 * O_MAX_BODIES + 4 * O_MAX_CONTACTS];
 static int probe_snapshot(o_world *w, island_t *is, int which) {
     f32 *o = t_probe[which];
@@ -1887,7 +1888,7 @@ static void probe_record(int it, int maxIt) {
     __atomic_fetch_add(&g_probe_hist[it], 1, __ATOMIC_RELAXED);
 }
 void rem2d_oracle_probe_toi(int *out, int reset) {
-    for (int p = 0; p < 5; ++p)
+    for (int p = 0; p <= PROBE_TOI_P; ++p)
         for (int i = 0; i < 256; ++i) { out[p * 256 + i] = g_probe_toi[p][i]; if (reset) g_probe_toi[p][i] = 0; }
 }
 void rem2d_oracle_probe_hist(int *out, int reset) {
@@ -2684,19 +2685,19 @@ static void island_solve_toi(o_world *w, island_t *is, const step_t *subStep, in
     w->bodies[is->bodies[toiIndexB]].a0 = is->positions[toiIndexB].a;
     contact_solver_init_velocity(w, is);
 #ifdef REM2D_ORACLE_PROBE
-    {   /* diagnostic: after how many sweeps does the TOI sub-step's state revisit a state of 1..4 sweeps ago? */
-        static _Thread_local f32 ring[5][8 + 4 * B2_MAX_TOI_CONTACTS];
+    {   /* diagnostic: after how many sweeps does the TOI sub-step's state revisit a state of 1..PROBE_TOI_P sweeps ago? */
+        static _Thread_local f32 ring[PROBE_TOI_P + 1][8 + 4 * B2_MAX_TOI_CONTACTS];
         int found = 0;
         for (int i = 0; i < subStep->velocityIterations; ++i) {
             contact_solver_solve_velocity(is);
-            f32 *o = ring[i % 5];
+            f32 *o = ring[i % (PROBE_TOI_P + 1)];
             int n = 0;
             o[n++] = is->velocities[0].v.x; o[n++] = is->velocities[0].v.y; o[n++] = is->velocities[0].w;
             for (int c = 0; c < is->ncontact; ++c)
                 for (int k = 0; k < is->vcs[c].pointCount; ++k) { o[n++] = is->vcs[c].points[k].normalImpulse; o[n++] = is->vcs[c].points[k].tangentImpulse; }
             if (!found)
-                for (int p = 1; p <= 4 && p <= i; ++p)
-                    if (memcmp(ring[i % 5], ring[(i - p) % 5], (size_t)n * sizeof(f32)) == 0) {
+                for (int p = 1; p <= PROBE_TOI_P && p <= i; ++p)
+                    if (memcmp(ring[i % (PROBE_TOI_P + 1)], ring[(i - p) % (PROBE_TOI_P + 1)], (size_t)n * sizeof(f32)) == 0) {
                         __atomic_fetch_add(&g_probe_toi[p][i < 255 ? i : 255], 1, __ATOMIC_RELAXED);
                         found = 1;
                         break;
