@@ -113,7 +113,7 @@ def build_population(workload, n_envs, rank):
             parts = None
     maker = synthetic.cppn_specs if workload == "cppn_hardcore" else synthetic.lsystem_specs
     if parts is None:
-        n_proc = max(1, min(8, os.cpu_count() or 1))
+        n_proc = max(1, min(8 if n_envs <= 131072 else 32, os.cpu_count() or 1))
         chunks = np.array_split(seeds, n_proc * 8)
         if os.environ.get("REM2D_BENCH_NO_FORK"):
             parts = [maker(c.tolist()) for c in chunks]
