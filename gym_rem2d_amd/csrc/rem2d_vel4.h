@@ -281,12 +281,14 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
     lds_sync();
-    // ---- the tile's contact phase: the phase inside the window of the most touching bodies (ties: the later phase,
-    // the host's own preference).  Bodies whose window holds it run all their manifolds there, one per sub-slot; the
-    // others run theirs in the first tick of their window.
-    int wlo[PASSES], wlen[PASSES], cover[V4_PHASES];
-#pragma unroll
-    for (int s = 0; s < V4_PHASES; ++s) cover[s] = 0;
+    // ---- contact phases of the tile.  A contact sub-slot costs the wavefront the same whether one manifold or 64 run in
+    // it, and a tick costs as many sub-slots as the most manifolds any body runs in it, so the bodies are gathered in as
+    // few phases as possible: greedily, the phase inside the window of the most still unplaced touching bodies (ties:
+    // the later phase, the host's own preference) takes all of those, until every body is placed (<= P rounds; counting
+    // the bodies with the most manifolds first made no difference).  A body runs all its manifolds in its tick, one per
+    // sub-slot.
+    int wlo[PASSES], wlen[PASSES], offB[PASSES];
+    bool placed[PASSES];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
@@ -295,17 +297,37 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         const int lastB = sh.lastR[bl];
         wlo[p] = lastB >= 0 ? lastB : 0;                          // first tick of the window (iteration 0)
         wlen[p] = lastB >= 0 ? sh.firstR[bl] + P - lastB : P;     // its length in ticks, 1 .. P
-        const int wl = wlo[p] % P;
+        offB[p] = wlo[p];
+        placed[p] = nT == 0;
+    }
+    for (int round = 0; round < V4_PHASES; ++round) {
+        int cover[V4_PHASES];
 #pragma unroll
-        for (int s = 0; s < V4_PHASES; ++s) {
-            int d = s - wl;
-            d = d < 0 ? d + P : d;
-            cover[s] += __popcll(__ballot(nT > 0 && s < P && d < wlen[p]));
+        for (int s = 0; s < V4_PHASES; ++s) cover[s] = 0;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int wl = wlo[p] % P;
+#pragma unroll
+            for (int s = 0; s < V4_PHASES; ++s) {
+                int d = s - wl;
+                d = d < 0 ? d + P : d;
+                cover[s] += __popcll(__ballot(!placed[p] && s < P && d < wlen[p]));
+            }
+        }
+        int cstar = 0;
+#pragma unroll
+        for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
+        if (cover[cstar] == 0) break; // wave-uniform: every touching body has its tick
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int dstar = cstar - wlo[p] % P;
+            dstar = dstar < 0 ? dstar + P : dstar;
+            if (!placed[p] && dstar < wlen[p]) {
+                offB[p] = wlo[p] + dstar;
+                placed[p] = true;
+            }
         }
     }
-    int cstar = 0;
-#pragma unroll
-    for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
 
     int NC = 0, lastTick = -1, maxRound = -1, err = 0, maxT = 0;
     int jcount[SETS]; // lanes handed out in every register set (the phases ph = s mod SETS share set s)
@@ -333,9 +355,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             jcount[s] += __popcll(m);
         }
         if (hasJ && phase >= V4_PHASES) err = REM2D_ERR_SOLVER_OVERFLOW;
-        int dstar = cstar - wlo[p] % P;
-        dstar = dstar < 0 ? dstar + P : dstar;
-        const int off = wlo[p] + (dstar < wlen[p] ? dstar : 0); // the tile's contact phase if the window holds it
+        const int off = offB[p];
         const int cph = off % P;
         if (nT > 0) {
 #pragma unroll
