@@ -69,11 +69,11 @@ struct JointT {
 #define V4_JPHASE(k) (((k) >> 26) & 0x7)
 #define V4_VALID(k) ((k) < 0)
 
-DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, int P, JointT &J) {
+DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, int P, int rotation, JointT &J) {
     const unsigned Lp = S.Lp;
     const unsigned gl = tb0 + (unsigned)child;
     const int jA = (child & ~(K - 1)) + LI(L_PARENT);
-    const int jround = LI(L_JROUND) & 0xff;
+    const int jround = (LI(L_JROUND) & 0xff) + rotation; // (its creature's schedule runs `rotation` ticks late)
     const unsigned jb = (unsigned)SCR_JREC_BASE * Lp + gl;
     J.rA = mk(SW(jb, 0), SW(jb, 1));
     J.rB = mk(SW(jb, 2), SW(jb, 3));
@@ -281,13 +281,17 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
     lds_sync();
-    // ---- contact phases of the tile.  A contact sub-slot costs the wavefront the same whether one manifold or 64 run in
-    // it, and a tick costs as many sub-slots as the most manifolds any body runs in it, so the bodies are gathered in as
-    // few phases as possible: greedily, the phase inside the window of the most still unplaced touching bodies (ties:
-    // the later phase, the host's own preference) takes all of those, until every body is placed (<= P rounds; counting
-    // the bodies with the most manifolds first made no difference).  A body runs all its manifolds in its tick, one per
-    // sub-slot.
-    int wlo[PASSES], wlen[PASSES], offB[PASSES];
+    // ---- contact phases.  A contact sub-slot costs the wavefront the same whether one manifold or 64 run in it, and a tick
+    // costs as many sub-slots as the most manifolds any body runs in it.  Two steps keep that sum small:
+    // (1) per creature, its bodies are gathered in as few phases as possible: greedily, the phase inside the window of the
+    //     most still unplaced touching bodies of the creature (ties: the later phase, the host's own preference) takes
+    //     all of those, until every body is placed (<= P rounds).  A body runs all its manifolds in its tick, one per
+    //     sub-slot.
+    // (2) creatures are independent, so each one may run its whole schedule -- joint rounds and contact ticks alike --
+    //     any number of ticks late: every creature is rotated so that its heaviest contact phase (the most manifolds on
+    //     one body) falls on phase 0 of the tile.  Only with one joint register set: the host packed the others by phase.
+    const unsigned long long groupLanes = (K >= WAVE ? ~0ull : ((1ull << K) - 1ull)) << (lane & ~(K - 1) & (WAVE - 1));
+    int wlo[PASSES], wlen[PASSES], offB[PASSES], delta[PASSES];
     bool placed[PASSES];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
@@ -299,35 +303,46 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         wlen[p] = lastB >= 0 ? sh.firstR[bl] + P - lastB : P;     // its length in ticks, 1 .. P
         offB[p] = wlo[p];
         placed[p] = nT == 0;
+        delta[p] = 0;
     }
-    for (int round = 0; round < V4_PHASES; ++round) {
-        int cover[V4_PHASES];
 #pragma unroll
-        for (int s = 0; s < V4_PHASES; ++s) cover[s] = 0;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int wl = wlo[p] % P;
+    for (int p = 0; p < PASSES; ++p) {
+        const int wl = wlo[p] % P;
+        for (int round = 0; round < P && round < V4_PHASES; ++round) { // per creature (the lanes of groupLanes)
+            int cover[V4_PHASES];
 #pragma unroll
             for (int s = 0; s < V4_PHASES; ++s) {
                 int d = s - wl;
                 d = d < 0 ? d + P : d;
-                cover[s] += __popcll(__ballot(!placed[p] && s < P && d < wlen[p]));
+                cover[s] = __popcll(__ballot(!placed[p] && s < P && d < wlen[p]) & groupLanes);
             }
-        }
-        int cstar = 0;
+            int cstar = 0;
 #pragma unroll
-        for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
-        if (cover[cstar] == 0) break; // wave-uniform: every touching body has its tick
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            int dstar = cstar - wlo[p] % P;
+            for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
+            int dstar = cstar - wl;
             dstar = dstar < 0 ? dstar + P : dstar;
-            if (!placed[p] && dstar < wlen[p]) {
+            if (!placed[p] && cover[cstar] > 0 && dstar < wlen[p]) {
                 offB[p] = wlo[p] + dstar;
                 placed[p] = true;
             }
         }
+        if (SETS == 1) {
+            const bool solve = (misc[p] & 0x100) != 0;
+            const int nT = solve ? (misc[p] & 0xff) : 0;
+            const int cph = offB[p] % P;
+            int heavyPhase = 0, heavy = 0; // the creature's phase with the most manifolds on one body (ties: the first)
+#pragma unroll
+            for (int s = 0; s < V4_PHASES; ++s) {
+                int most = 0;
+#pragma unroll
+                for (int n = 1; n <= KT; ++n) most = (__ballot(nT >= n && cph == s) & groupLanes) ? n : most;
+                if (s < P && most > heavy) { heavy = most; heavyPhase = s; }
+            }
+            delta[p] = heavy > 0 ? (P - heavyPhase) % P : 0;
+        }
+        sh.firstR[p * WAVE + lane] = delta[p]; // (the windows are done with: the joint role reads its creature's rotation here)
     }
+    lds_sync();
 
     int NC = 0, lastTick = -1, maxRound = -1, err = 0, maxT = 0;
     int jcount[SETS]; // lanes handed out in every register set (the phases ph = s mod SETS share set s)
@@ -342,7 +357,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         const bool solve = (misc[p] & 0x100) != 0;
         const bool hasJ = solve && parent[p] >= 0;
         const int nT = solve ? (misc[p] & 0xff) : 0;
-        const int jr = sched[p] & 0xff;
+        const int jr = (sched[p] & 0xff) + delta[p];
         const int phase = jr % P;
 #pragma unroll
         for (int s = 0; s < SETS; ++s) {
@@ -355,7 +370,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             jcount[s] += __popcll(m);
         }
         if (hasJ && phase >= V4_PHASES) err = REM2D_ERR_SOLVER_OVERFLOW;
-        const int off = offB[p];
+        const int off = offB[p] + delta[p];
         const int cph = off % P;
         if (nT > 0) {
 #pragma unroll
@@ -387,7 +402,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     for (int s = 0; s < SETS; ++s) {
         J[s].key = 0;
         const int child = sh.jmap[s][lane];
-        if (child != 0xffff) v4_joint_load(S, tb0, K, child, h, P, J[s]);
+        if (child != 0xffff) v4_joint_load(S, tb0, K, child, h, P, sh.firstR[child], J[s]);
     }
     // ---------------- contact role: manifold `lane + 64 cs` of the tile; beyond CSETS * 64 through scratch ----------------
     ContactT C[CSETS];
