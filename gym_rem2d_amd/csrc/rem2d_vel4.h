@@ -473,7 +473,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     {
         const int span = iters * P; // joint k fires at ticks jround + i P, i < iters, i.e. while tick - jround < span
         const bool joints = !(V4_DBG(A) & 2);
-        const bool stamp = (V4_DBG(A) & 8) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py)
+        const bool stamp = (V4_DBG(A) & (8 | 32)) != 0; // diagnostic: s_memtime split of the loop (tools/vel4_probe.py); 32: four packed words
         unsigned long long tJ = 0, tC = 0, t0 = 0, t1 = 0, nSub = 0;
         const unsigned long long tStart = stamp ? __builtin_amdgcn_s_memtime() : 0;
         const unsigned long long rStart = stamp ? __builtin_amdgcn_s_memrealtime() : 0; // constant 100 MHz
@@ -494,7 +494,15 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                 }
             }
         }
-        if (stamp && lane == 0 && c1 - c0 >= 5) { // debug words in the (otherwise unused while stepping) TOI event counters
+        if ((V4_DBG(A) & 32) && lane == 0 && c1 - c0 >= 4) { // the same for tiles of four creatures (tools/slow_tiles_probe.py)
+            const unsigned long long tAll = __builtin_amdgcn_s_memtime() - tStart;
+            unsigned env = (unsigned)c0;
+            EI(E_TOIEVENTS) = (int)(tJ >> 6);
+            env = (unsigned)c0 + 1; EI(E_TOIEVENTS) = (int)(tC >> 6);
+            env = (unsigned)c0 + 2; EI(E_TOIEVENTS) = (int)(tAll >> 6);
+            env = (unsigned)c0 + 3; EI(E_TOIEVENTS) = (int)((nSub << 16) | (unsigned long long)(nTicks & 0xffff));
+        }
+        if ((V4_DBG(A) & 8) && lane == 0 && c1 - c0 >= 5) { // debug words in the (otherwise unused while stepping) TOI event counters
             const unsigned long long tAll = __builtin_amdgcn_s_memtime() - tStart;
             unsigned env = (unsigned)c0;
             EI(E_TOIEVENTS) = (int)(tJ >> 4);

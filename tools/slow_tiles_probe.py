@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Scratch probe (GPU box, -DREM2D_V4_PROBES build via REM2D_LIB_PATH, REM2D_V4_DBG=8): the slowest tiles of the velocity
-kernel in the 8-lane bucket of config 3 -- ticks, contact sub-slots, cycles per slot, and what their creatures look like."""
+"""Scratch probe (GPU box, -DREM2D_V4_PROBES build via REM2D_LIB_PATH, REM2D_V4_DBG=32): the slowest tiles of the velocity
+kernel in one lane bucket of config 3 (argument: lanes, default 8) -- ticks, contact sub-slots, cycles per slot, and what their creatures look like."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -21,10 +21,11 @@ torch.cuda.synchronize()
 ev = w.view("toievents").cpu().numpy().reshape(-1).astype(np.float64)
 tiles = np.asarray(w.tiles)
 t = tiles[:-1]
-ok = (np.diff(tiles) >= 5) & (t + 5 <= m.n_envs)
+ok = (np.diff(tiles) >= 4) & (t + 4 <= m.n_envs)
 t, te = t[ok], tiles[1:][ok]
-tj, tc, ta, ns, nk = (ev[t + i] for i in range(5))
-tj, tc, ta = tj * 16, tc * 16, ta * 16
+tj, tc, ta, packed = (ev[t + i] for i in range(4))   # REM2D_V4_DBG=32: cycles / 64, sub-slots << 16 | ticks
+tj, tc, ta = tj * 64, tc * 64, ta * 64
+ns, nk = np.floor(packed / 65536), packed % 65536
 nt = (w.view("cinfo").cpu().numpy() & 0xff) > 0           # [slots, envs, lanes] touching
 man = nt.sum(0)                                            # manifolds per body
 jr = m.arrays["jround"].reshape(m.n_envs, K)
