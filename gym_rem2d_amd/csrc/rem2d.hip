@@ -120,6 +120,11 @@ struct rem2d_world {
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
 //   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
 struct TileShape { int sets, passes, csets; };
+// bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel (rem2d_kernels.h); REM2D_HEAVY_PER_WAVE, 1..64
+static int heavy_per_wave() {
+    static const int n = getenv("REM2D_HEAVY_PER_WAVE") ? atoi(getenv("REM2D_HEAVY_PER_WAVE")) : 2;
+    return n < 1 ? 1 : (n > WAVE ? WAVE : n);
+}
 static int tile_shape_id() {
     static const int id = getenv("REM2D_TILE_SHAPE") ? atoi(getenv("REM2D_TILE_SHAPE")) : 3;
     return (id == 0 || id == 1) ? id : 3;
@@ -589,6 +594,7 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
+    A.heavyPerWave = heavy_per_wave();
     A.defer = continuous ? 2 : 0; // 2: post runs the TOI scan itself (the fused kernel's path keeps 1 = separate scan kernel)
     Vel4Args V;
     V.velIters = vel_iters;
@@ -644,6 +650,7 @@ static int step_fused(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
+    A.heavyPerWave = heavy_per_wave();
     A.defer = continuous ? 1 : 0;
     dim3 grid(blocks), block(WAVE);
     const int launches = continuous ? n_steps : 1;

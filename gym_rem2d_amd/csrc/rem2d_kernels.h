@@ -34,7 +34,7 @@ DEV void env_bookkeeping(const State &S, unsigned env, int sub, float rootx) {
 // =====================================================================================
 // the step kernel
 // =====================================================================================
-struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ };
+struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ int heavyPerWave; };
 
 // Register budget: what the 180-iteration velocity loop touches stays in VGPRs (body velocity,
 // joint effective-mass terms and impulses, KR contact constraints); everything else (pose
@@ -573,9 +573,17 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
 }
 template <int K>
 DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, ToiShared &ts) {
-    const unsigned idx = block * WAVE + threadIdx.x;
-    if (block * WAVE >= (unsigned)S.toiWork[0]) return;
-    if (idx >= (unsigned)S.toiWork[0]) return;
+    // Bodies per wavefront: the lanes of a wavefront run the event loop in lockstep -- every b2TimeOfImpact any lane needs at
+    // any pair slot, the 180 sweeps of a sub-step as soon as one lane's does not reach its fixed point, as many rounds as
+    // the lane with the most events -- so a full wavefront costs about twice its slowest body.  The list is short (about
+    // 1 % of the bodies): it is dealt out REM2D_HEAVY_PER_WAVE bodies to a wavefront, more only when it is so long that
+    // the grid would not cover it (the landing after a reset).
+    const unsigned queued = (unsigned)S.toiWork[0], blocks = S.Lp / WAVE;
+    unsigned per = (queued + blocks - 1) / blocks;
+    per = per < (unsigned)A.heavyPerWave ? (unsigned)A.heavyPerWave : per;
+    const unsigned idx = block * per + threadIdx.x;
+    if (block * per >= queued) return;
+    if (threadIdx.x >= per || idx >= queued) return;
     const unsigned gl = (unsigned)S.toiWork[16 + idx];
     const unsigned env = gl / K;
     const int shape = LI(L_SHAPE);
