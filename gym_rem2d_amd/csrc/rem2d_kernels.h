@@ -581,9 +581,12 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     const unsigned queued = (unsigned)S.toiWork[0], blocks = S.Lp / WAVE;
     unsigned per = (queued + blocks - 1) / blocks;
     per = per < (unsigned)A.heavyPerWave ? (unsigned)A.heavyPerWave : per;
-    const unsigned idx = block * per + threadIdx.x;
     if (block * per >= queued) return;
-    if (threadIdx.x >= per || idx >= queued) return;
+    unsigned G = 1; // lanes per body: the largest power of two that fits (rem2d_toi.h: the alpha pass runs a body's pairs side by side)
+    while (G * 2 * per <= WAVE) G *= 2;
+    const unsigned sub = threadIdx.x & (G - 1), slot = threadIdx.x / G;
+    const unsigned idx = block * per + slot;
+    if (slot >= per || idx >= queued) return;
     const unsigned gl = (unsigned)S.toiWork[16 + idx];
     const unsigned env = gl / K;
     const int shape = LI(L_SHAPE);
@@ -592,7 +595,8 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     B.px = LF(L_PX); B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
     B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
     B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
-                       SW(wb, 2), B, ts, (int)threadIdx.x);
+                       SW(wb, 2), B, ts, (int)threadIdx.x, (int)sub, (int)G);
+    if (sub != 0) return; // the body's other lanes hold the same result
     LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
     LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
     if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);

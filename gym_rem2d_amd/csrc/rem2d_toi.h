@@ -494,7 +494,11 @@ DEV void island_store(ToiShared &ts, int lane, int t, const Manifold &m) {
 #define IW(t, k) (ts.m[(t) * SCR_WORDS + (k)][lane])
 DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int shape, float hx, float hy, float mB, float iB,
                                                 float h, int velIters, float c0x, float c0y, float a0, LaneBody B,
-                                                ToiShared &ts, int lane) {
+                                                ToiShared &ts, int lane, int sub, int G) {
+    // sub / G: the G lanes (a power of two, G-aligned) that carry this body.  All of them run this function on the same
+    // values -- so every store below writes the same word G times, harmless -- except in the alpha pass, where lane `sub`
+    // takes the pair slots sub, sub + G, ...: the b2TimeOfImpact calls of a body run side by side instead of one after
+    // the other, and a reduction hands every lane the same (smallest alpha, first slot) the sequential scan finds.
     const bool sleepResetAlways = (S.flags & REM2D_FLAG_SLEEP_RESET_ALWAYS) != 0;
     const float radiusB = shape == SHAPE_CIRCLE ? hx : B2_POLYGON_RADIUS;
     const float friction = T.friction;
@@ -518,7 +522,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
     for (;;) {
         int minSlot = -1;
         float minAlpha = 1.0f;
-        for (int s = 0; s < B.cCount; ++s) {
+        for (int s = sub; s < B.cCount; s += G) {
             unsigned o = (unsigned)s * Lp + gl;
             int info = CI(C_INFO, o);
             if (!(info & CI_ENABLED)) continue;
@@ -546,6 +550,12 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 CI(C_INFO, o) = info | CI_TOIFLAG;
             }
             if (alpha < minAlpha) { minSlot = s; minAlpha = alpha; }
+        }
+        if (G > 1) __threadfence_block(); // the flags and alphas a lane stored for its slots are read by the body's other lanes below
+        for (int o = 1; o < G; o <<= 1) { // smallest alpha of the body's lanes; among equal ones the first slot (the scan's choice)
+            const float a2 = __shfl_xor(minAlpha, o);
+            const int s2 = __shfl_xor(minSlot, o);
+            if (s2 >= 0 && (a2 < minAlpha || (a2 == minAlpha && (minSlot < 0 || s2 < minSlot)))) { minAlpha = a2; minSlot = s2; }
         }
         TOI_STAMP(0); // alpha pass: b2TimeOfImpact of every pair whose TOI is not cached
         if (minSlot < 0 || 1.0f - 10.0f * B2_EPSILON < minAlpha) break;
