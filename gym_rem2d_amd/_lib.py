@@ -128,6 +128,7 @@ def lib():
     L.rem2d_plan_tiles_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     L.rem2d_world_set_tile_shape.argtypes = [C.c_void_p, C.c_int32]
+    L.rem2d_world_adopt.argtypes = [C.c_void_p]
     L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
     L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
@@ -144,7 +145,7 @@ def lib():
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 4:
+    if L.rem2d_abi_version() != 5:
         raise Rem2dError("librem2d.so ABI version mismatch")
     _lib = L
     return L

@@ -234,6 +234,13 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     return REM2D_OK;
 }
 
+extern "C" int rem2d_world_adopt(rem2d_world *w) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if (!w->haveTerrain) return fail(REM2D_E_STATE, "rem2d_world_set_terrain must be called before adopt");
+    w->haveReset = true; // the arena is the whole state between two steps: the scratch is rewritten by every step
+    return REM2D_OK;
+}
+
 extern "C" int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_t *done_dev, const int32_t *index_dev) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
     if ((reward_dev == nullptr) != (done_dev == nullptr) || (reward_dev == nullptr) != (index_dev == nullptr))

@@ -123,6 +123,10 @@ class BatchedModular2D:
         for w, _ in self.worlds:
             w.close()
         self.worlds = []
+        self._world_morph = []   # host-side layout of every world's creatures (compact() re-plans tiles from it)
+        self._compacted = False
+        self._inactive = set()   # worlds compact() found without a single open fitness
+        self._tile_shape_used = None
         self.n_envs = n_envs
         self.streams = []
         # Step groups: with continuous physics every step ends in the TOI kernels, a long tail of a few busy
@@ -141,6 +145,7 @@ class BatchedModular2D:
         shape = self.tile_shape
         if shape is None and "REM2D_TILE_SHAPE" not in os.environ:
             shape = 0 if n_envs >= self.BIG_POPULATION else 3
+        self._tile_shape_used = shape
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
@@ -157,6 +162,7 @@ class BatchedModular2D:
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
                 self.worlds.append((w, torch.as_tensor(idx[lo:hi], dtype=torch.long, device=w.device)))
+                self._world_morph.append(part)
                 # fallback path (REM2D_MERGED_LAUNCH=0): one HIP stream per world
                 self.streams.append(torch.cuda.Stream(device=w.device))
         self.groups = [g for g in self.groups if g]
@@ -165,6 +171,9 @@ class BatchedModular2D:
         self._reward = torch.zeros(n_envs, dtype=torch.float32, device=dev)
         self._done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
         self._fitness = torch.zeros(n_envs, dtype=torch.float64, device=dev)
+        self._frozen_pop = torch.zeros(n_envs, dtype=torch.int32, device=dev)
+        self._steps_pop = torch.zeros(n_envs, dtype=torch.int32, device=dev)
+        self._err_pop = torch.zeros(n_envs, dtype=torch.int32, device=dev)
         if len(self.worlds) > 1:
             # the kernels write reward / done straight into these population-order arrays (rem2d_world_set_outputs):
             # step() returns them without a gather per world
@@ -210,23 +219,76 @@ class BatchedModular2D:
                     cur.wait_stream(st)
         else:
             cur = torch.cuda.current_stream(self.worlds[0][0].device)
-            for (w, _), st in zip(self.worlds, self.streams):
+            for wi, ((w, _), st) in enumerate(zip(self.worlds, self.streams)):
+                if wi in self._inactive:
+                    continue
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     w.step(n_steps)
             for st in self.streams:
                 cur.wait_stream(st)
-        if len(self.worlds) == 1:
+        if len(self.worlds) == 1 and not self._compacted:
             w = self.worlds[0][0]
             return w.view("reward"), w.view("done") != 0
         return self._reward, self._done   # written by the step's own kernels (set_outputs in _upload)
 
     def _gather(self, name, out):
-        if len(self.worlds) == 1:
+        if len(self.worlds) == 1 and not self._compacted:
             return self.worlds[0][0].view(name)
-        for w, idx in self.worlds:
+        for w, idx in self.worlds:   # (creatures compact() has dropped keep the values it stored in `out`)
             out.index_copy_(0, idx, w.view(name).to(out.dtype))
         return out
+
+    # ---- evaluate(): drop the creatures whose fitness is final ----
+    def compact(self, min_envs=2048, max_alive=0.5):
+        """Between two steps of an evaluate() episode: every world in which at most ``max_alive`` of the creatures still
+        have an open fitness (REM2D_F_FROZEN == 0) is replaced by a smaller one that holds only those -- state moved
+        field by field, rem2d_world_adopt -- so that the wavefronts of the finished creatures stop costing anything
+        (REM2D_FLAG_SKIP_FROZEN only stops wavefronts whose creatures have ALL finished).  Fitness / steps / error bits
+        of the dropped creatures stay readable through the population-order properties.  Worlds with fewer than
+        ``min_envs`` creatures are left alone.  Returns the number of creatures still being stepped."""
+        alive_total = 0
+        for wi, (w, idx) in enumerate(self.worlds):
+            if wi in self._inactive:
+                continue
+            frozen = w.view("frozen")
+            keep = torch.nonzero(frozen == 0, as_tuple=False).flatten()
+            n_keep = int(keep.numel())
+            if w.n_envs < min_envs or n_keep > max_alive * w.n_envs:
+                alive_total += n_keep
+                continue
+            # what the population-order properties report for the creatures that leave
+            self._fitness.index_copy_(0, idx, w.view("fitness"))
+            self._frozen_pop.index_copy_(0, idx, w.view("frozen"))
+            self._steps_pop.index_copy_(0, idx, w.view("steps"))
+            self._err_pop.index_copy_(0, idx, w.view("err"))
+            self._reward.index_copy_(0, idx, w.view("reward"))
+            self._done.index_copy_(0, idx, w.view("done") != 0)
+            self._compacted = True
+            if n_keep == 0:   # nobody left: the world stays as it is and is not launched any more
+                self._inactive.add(wi)
+                continue
+            keep_host = keep.cpu().numpy()
+            part = self._world_morph[wi].take(keep_host)
+            nw = BatchedWorld(n_keep, w.lanes, self.flags, self.device)
+            nw.set_terrain(self._terrain())
+            for name in _lib.FIELDS:
+                src, dst = w.view(name), nw.view(name)
+                dst.copy_(src.index_select(1 if src.dim() == 3 else 0, keep))
+            nw.adopt(part, tile_shape=self._tile_shape_used)
+            new_idx = idx[keep]
+            nw.set_outputs(self._reward, self._done, new_idx.to(torch.int32))
+            torch.cuda.synchronize(nw.device)   # the old arena must outlive the copies
+            w.close()
+            self.worlds[wi] = (nw, new_idx)
+            self._world_morph[wi] = part
+            alive_total += n_keep
+        if self._compacted:
+            self.groups = [[i for i in g if i not in self._inactive] for g in self.groups]
+            keep_g = [k for k, g in enumerate(self.groups) if g]
+            self.groups = [self.groups[k] for k in keep_g]
+            self.group_streams = [self.group_streams[k] for k in keep_g] or [None]
+        return alive_total
 
     @property
     def fitness(self):
@@ -235,18 +297,15 @@ class BatchedModular2D:
 
     @property
     def frozen(self):
-        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
-        return self._gather("frozen", out)
+        return self._gather("frozen", self._frozen_pop)
 
     @property
     def steps(self):
         """env steps taken since reset, int32 [N]."""
-        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
-        return self._gather("steps", out)
+        return self._gather("steps", self._steps_pop)
 
     def errors(self):
-        out = torch.zeros(self.n_envs, dtype=torch.int32, device=self._reward.device)
-        return self._gather("err", out)
+        return self._gather("err", self._err_pop)
 
     def close(self):
         for w, _ in self.worlds:

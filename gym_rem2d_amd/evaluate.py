@@ -82,16 +82,22 @@ def check_errors(env, on_error="raise"):
     return bad
 
 
-def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="raise"):
+def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="raise", compact=True):
     """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
     Returns fitness[N] (float64 tensor on the env's device).  Engine overflows (see SolverOverflow) are not silent:
-    by default they raise once the episode is over."""
+    by default they raise once the episode is over.  compact: in worlds created with REM2D_FLAG_SKIP_FROZEN (the
+    bodies of finished creatures are nobody's business any more) the survivors are moved into smaller worlds between
+    chunks once most of a world has finished (BatchedModular2D.compact) -- same fitness, a shorter episode."""
     done_steps = 0
+    compact = compact and bool(env.flags & _lib.FLAG_SKIP_FROZEN)
     while done_steps < max_steps:
         n = min(chunk, max_steps - done_steps)
         env.step(n)
         done_steps += n
-        if bool((env.frozen != 0).all()):
+        if compact:
+            if env.compact() == 0:
+                break
+        elif bool((env.frozen != 0).all()):
             break
     check_errors(env, on_error)
     return env.fitness.clone()

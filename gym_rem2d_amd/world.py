@@ -85,6 +85,21 @@ class BatchedWorld:
                                      self.n_envs_padded, tile_shape=self.tile_shape)
         _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
+    def adopt(self, morph: Morphology, tile_shape=None):
+        """Instead of reset(): the caller has filled every state field of this world (``view(name)`` for all of
+        ``_lib.FIELDS``) from another world between two steps (include/rem2d.h, rem2d_world_adopt).  ``morph``: the
+        host-side layout of the creatures now in this world, for the tile plan of the velocity kernel."""
+        if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
+            raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %
+                             (morph.n_envs, morph.lanes, self.n_envs, self.lanes))
+        _lib.check(_lib.lib().rem2d_world_adopt(self.h))
+        if tile_shape is not None:
+            _lib.check(_lib.lib().rem2d_world_set_tile_shape(self.h, int(tile_shape)))
+            self.tile_shape = int(tile_shape)
+        self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
+                                     self.n_envs_padded, tile_shape=self.tile_shape)
+        _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
+
     def set_outputs(self, reward, done, index):
         """Let the kernels also write reward / done of creature e to reward[index[e]] / done[index[e]] (population
         order; `done` is a torch.bool tensor, `index` int32 on the device).  The tensors are kept alive here."""

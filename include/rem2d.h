@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 4 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
-                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape */
+#define REM2D_ABI_VERSION 5 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt */
 
 enum {
     REM2D_OK = 0,
@@ -132,6 +132,15 @@ int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const float *ys, in
 /* Modular2D.reset (Modular2DEnv.py:565-598): destroy + re-create every world and build the
  * robots (create_robot :517-563) from the uploaded layout; wall of death back to 0. */
 int rem2d_world_reset(rem2d_world *w, const rem2d_morph *morph_dev, void *stream);
+
+/* Instead of rem2d_world_reset: the caller has filled EVERY field of the state arena itself, creature by creature, from the
+ * arena of another world of the same lane count, terrain and flags between two steps (the fields of rem2d_world_field:
+ * all of a creature's lanes, pair slots and per-creature words; padding creatures zero) -- e.g. the survivors of an
+ * evaluate() episode moved into a smaller world, so that the wavefronts of the dead stop costing anything
+ * (gym_rem2d_amd.env.BatchedModular2D.compact).  No counterpart in the reference (a b2World cannot be copied); the
+ * creatures continue bit-identically because nothing outside the arena survives a step.  Follow with
+ * rem2d_world_set_tiles for the new creature order. */
+int rem2d_world_adopt(rem2d_world *w);
 
 /* A population that lives in several worlds (one per lane count) reads reward / done in POPULATION order: with these
  * caller-owned device arrays set, every env-step also writes creature e's reward (float) and done (0 / 1 byte, the

@@ -158,6 +158,10 @@ int rem2d_cpu_world_set_tiles(rem2d_cpu_world *w, const int32_t *tile_start, int
     (void)tile_start; (void)n_tiles;
     return w ? REM2D_OK : c_fail(REM2D_E_INVALID, "world is NULL"); /* a launch shape: nothing to do on the CPU */
 }
+int rem2d_cpu_world_adopt(rem2d_cpu_world *w) {
+    (void)w; /* the twin's state lives in its oracle worlds, not in the arena: there is nothing it could adopt */
+    return c_fail(REM2D_E_INVALID, "rem2d_cpu_world_adopt: not supported by the host-pointer twin");
+}
 int rem2d_cpu_world_set_tile_shape(rem2d_cpu_world *w, int32_t tile_shape) {
     if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
     if (tile_shape != 0 && tile_shape != 1 && tile_shape != 3) return c_fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");

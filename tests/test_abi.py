@@ -35,7 +35,7 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 4
+    assert L.rem2d_abi_version() == 5
     cfg = lib.WorldCfg(65536, 8, 0, 0)
     n = L.rem2d_state_bytes(C.byref(cfg))
     # every field is per lane / per slot / per creature: a few hundred bytes per body

@@ -149,6 +149,54 @@ def test_skip_frozen_keeps_fitness_and_stops_stepping(need_gpu):
     assert s1.max() <= s0.max() and (s1 < s0).mean() > 0.3   # with it, most creatures stopped early
 
 
+def test_compaction_of_the_survivors_keeps_every_fitness(need_gpu):
+    """BatchedModular2D.compact (rem2d_world_adopt): between the chunks of an episode the creatures whose fitness is
+    still open move into smaller worlds, state field by field; every fitness, frozen flag and error word is the one the
+    uncompacted episode gives, for single- and multi-world populations, and the worlds do shrink."""
+    import torch
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import run_episode
+    from gym_rem2d_amd.population import LSystemPopulation
+    rng = np.random.default_rng(7)
+    pop = LSystemPopulation.random(3000, rng, max_modules=15)
+    flags = _lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN
+    for batches in (pop.compile(2), [pop.compile(2)[-1]]):   # every lane bucket / the widest bucket alone (one world)
+        n = sum(len(idx) for _, idx in batches)
+        remap = {int(e): k for k, e in enumerate(np.concatenate([np.asarray(idx) for _, idx in batches]))}
+        batches = [(m, [remap[int(e)] for e in idx]) for m, idx in batches]
+        ref_env = BatchedModular2D(flags=flags)
+        ref_env._upload(batches, n)
+        ref = run_episode(ref_env, max_steps=600, compact=False)
+        ref_frozen, ref_err = ref_env.frozen.clone(), ref_env.errors().clone()
+        ref_env.close()
+        env = BatchedModular2D(flags=flags)
+        env._upload(batches, n)
+        sizes = [sum(w.n_envs for w, _ in env.worlds)]
+        done_steps, alive = 0, n
+        while done_steps < 600 and alive > 0:
+            env.step(50)
+            done_steps += 50
+            alive = env.compact(min_envs=32, max_alive=0.8)
+            sizes.append(sum(w.n_envs for wi, (w, _) in enumerate(env.worlds) if wi not in env._inactive))
+        assert torch.equal(env.fitness, ref)
+        assert torch.equal(env.frozen, ref_frozen) and torch.equal(env.errors(), ref_err)
+        assert sizes[-1] < 0.2 * sizes[0], sizes            # most creatures were dropped along the way
+        rew, done = env.step(1) if alive else (env._reward, env._done)
+        assert rew.shape[0] == n and done.shape[0] == n     # population order and size survive the compaction
+        env.close()
+    # the default path of run_episode compacts by itself and returns the same fitness
+    env = BatchedModular2D(flags=flags)
+    env._upload(pop.compile(2), len(pop))
+    a = run_episode(env, max_steps=600)
+    env.close()
+    env = BatchedModular2D(flags=flags)
+    env._upload(pop.compile(2), len(pop))
+    b = run_episode(env, max_steps=600, compact=False)
+    env.close()
+    assert torch.equal(a, b)
+
+
 def test_bench_json_contract(need_gpu):
     """bench.py prints exactly one JSON line with the fields the driver reads (tiny sizes here)."""
     import json
