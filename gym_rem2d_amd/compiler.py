@@ -336,6 +336,19 @@ class Morphology:
         m.n_bodies[:] = self.n_bodies[idx]
         return m
 
+    @classmethod
+    def concat(cls, parts):
+        """The creatures of several batches of one lane count, one after the other."""
+        parts = list(parts)
+        lanes = parts[0].lanes
+        if any(p.lanes != lanes for p in parts):
+            raise ValueError("Morphology.concat needs batches of one lane count")
+        m = cls(sum(p.n_envs for p in parts), lanes)
+        for k in m.arrays:
+            m.arrays[k][:] = np.concatenate([p.arrays[k] for p in parts])
+        m.n_bodies[:] = np.concatenate([p.n_bodies for p in parts])
+        return m
+
     def as_dict(self):
         d = dict(self.arrays)
         d["n_envs"], d["lanes"] = self.n_envs, self.lanes

@@ -235,59 +235,73 @@ class BatchedModular2D:
     def _gather(self, name, out):
         if len(self.worlds) == 1 and not self._compacted:
             return self.worlds[0][0].view(name)
-        for w, idx in self.worlds:   # (creatures compact() has dropped keep the values it stored in `out`)
-            out.index_copy_(0, idx, w.view(name).to(out.dtype))
+        for wi, (w, idx) in enumerate(self.worlds):   # (creatures compact() has dropped keep the values it stored in `out`)
+            if wi not in self._inactive:
+                out.index_copy_(0, idx, w.view(name).to(out.dtype))
         return out
 
     # ---- evaluate(): drop the creatures whose fitness is final ----
     def compact(self, min_envs=2048, max_alive=0.5):
-        """Between two steps of an evaluate() episode: every world in which at most ``max_alive`` of the creatures still
-        have an open fitness (REM2D_F_FROZEN == 0) is replaced by a smaller one that holds only those -- state moved
-        field by field, rem2d_world_adopt -- so that the wavefronts of the finished creatures stop costing anything
-        (REM2D_FLAG_SKIP_FROZEN only stops wavefronts whose creatures have ALL finished).  Fitness / steps / error bits
-        of the dropped creatures stay readable through the population-order properties.  Worlds with fewer than
-        ``min_envs`` creatures are left alone.  Returns the number of creatures still being stepped."""
-        alive_total = 0
+        """Between two steps of an evaluate() episode: when at most ``max_alive`` of the creatures of a lane bucket still
+        have an open fitness (REM2D_F_FROZEN == 0), the bucket's worlds (one per step group) are replaced by ONE smaller
+        world that holds only those -- state moved field by field, rem2d_world_adopt -- so that the wavefronts of the
+        finished creatures stop costing anything (REM2D_FLAG_SKIP_FROZEN only stops wavefronts whose creatures have ALL
+        finished) and the few survivors of a long episode are stepped by one launch sequence instead of one per step
+        group.  Fitness / steps / error bits of the dropped creatures stay readable through the population-order
+        properties.  Buckets with fewer than ``min_envs`` creatures are left alone.  Returns the number of creatures
+        still being stepped."""
+        by_lanes = {}
         for wi, (w, idx) in enumerate(self.worlds):
-            if wi in self._inactive:
+            if wi not in self._inactive:
+                by_lanes.setdefault(w.lanes, []).append(wi)
+        alive_total = 0
+        changed = False
+        for lanes, wis in sorted(by_lanes.items()):
+            keeps = [torch.nonzero(self.worlds[wi][0].view("frozen") == 0, as_tuple=False).flatten() for wi in wis]
+            n_keep = sum(int(k.numel()) for k in keeps)
+            n_now = sum(self.worlds[wi][0].n_envs for wi in wis)
+            alive_total += n_keep
+            if n_now < min_envs or n_keep > max_alive * n_now:
                 continue
-            frozen = w.view("frozen")
-            keep = torch.nonzero(frozen == 0, as_tuple=False).flatten()
-            n_keep = int(keep.numel())
-            if w.n_envs < min_envs or n_keep > max_alive * w.n_envs:
-                alive_total += n_keep
+            changed = True
+            for wi in wis:   # what the population-order properties report for the creatures that leave
+                w, idx = self.worlds[wi]
+                self._fitness.index_copy_(0, idx, w.view("fitness"))
+                self._frozen_pop.index_copy_(0, idx, w.view("frozen"))
+                self._steps_pop.index_copy_(0, idx, w.view("steps"))
+                self._err_pop.index_copy_(0, idx, w.view("err"))
+                self._reward.index_copy_(0, idx, w.view("reward"))
+                self._done.index_copy_(0, idx, w.view("done") != 0)
+            if n_keep == 0:   # nobody left: the worlds stay as they are and are not launched any more
+                self._inactive.update(wis)
                 continue
-            # what the population-order properties report for the creatures that leave
-            self._fitness.index_copy_(0, idx, w.view("fitness"))
-            self._frozen_pop.index_copy_(0, idx, w.view("frozen"))
-            self._steps_pop.index_copy_(0, idx, w.view("steps"))
-            self._err_pop.index_copy_(0, idx, w.view("err"))
-            self._reward.index_copy_(0, idx, w.view("reward"))
-            self._done.index_copy_(0, idx, w.view("done") != 0)
-            self._compacted = True
-            if n_keep == 0:   # nobody left: the world stays as it is and is not launched any more
-                self._inactive.add(wi)
-                continue
-            keep_host = keep.cpu().numpy()
-            part = self._world_morph[wi].take(keep_host)
-            nw = BatchedWorld(n_keep, w.lanes, self.flags, self.device)
+            part = Morphology.concat([self._world_morph[wi].take(k.cpu().numpy()) for wi, k in zip(wis, keeps) if k.numel()])
+            nw = BatchedWorld(n_keep, lanes, self.flags, self.device)
             nw.set_terrain(self._terrain())
             for name in _lib.FIELDS:
-                src, dst = w.view(name), nw.view(name)
-                dst.copy_(src.index_select(1 if src.dim() == 3 else 0, keep))
+                dst = nw.view(name)
+                dim = 1 if dst.dim() == 3 else 0
+                dst.copy_(torch.cat([self.worlds[wi][0].view(name).index_select(dim, k) for wi, k in zip(wis, keeps)
+                                     if k.numel()], dim=dim))
             nw.adopt(part, tile_shape=self._tile_shape_used)
-            new_idx = idx[keep]
+            new_idx = torch.cat([self.worlds[wi][1][k] for wi, k in zip(wis, keeps) if k.numel()])
             nw.set_outputs(self._reward, self._done, new_idx.to(torch.int32))
-            torch.cuda.synchronize(nw.device)   # the old arena must outlive the copies
-            w.close()
-            self.worlds[wi] = (nw, new_idx)
-            self._world_morph[wi] = part
-            alive_total += n_keep
-        if self._compacted:
-            self.groups = [[i for i in g if i not in self._inactive] for g in self.groups]
-            keep_g = [k for k, g in enumerate(self.groups) if g]
-            self.groups = [self.groups[k] for k in keep_g]
-            self.group_streams = [self.group_streams[k] for k in keep_g] or [None]
+            torch.cuda.synchronize(nw.device)   # the old arenas must outlive the copies
+            for wi in wis[1:]:   # (their arenas are released; the entries stay so that world indices do not move)
+                self._inactive.add(wi)
+                self.worlds[wi][0].close()
+            self.worlds[wis[0]][0].close()
+            self.worlds[wis[0]] = (nw, new_idx)
+            self._world_morph[wis[0]] = part
+        if changed:
+            self._compacted = True
+            groups = [[i for i in g if i not in self._inactive] for g in self.groups]
+            groups = [g for g in groups if g]
+            active = [i for g in groups for i in g]
+            if sum(self.worlds[i][0].n_envs for i in active) < 16384 and len(active) <= _lib.MAX_WORLDS_PER_STEP:
+                groups = [active] if active else []   # too few creatures for step groups to pay: one launch sequence
+            self.groups = groups
+            self.group_streams = [torch.cuda.Stream(device=self._reward.device) for _ in groups] if len(groups) > 1 else [None]
         return alive_total
 
     @property

@@ -161,6 +161,7 @@ def test_compaction_of_the_survivors_keeps_every_fitness(need_gpu):
     rng = np.random.default_rng(7)
     pop = LSystemPopulation.random(3000, rng, max_modules=15)
     flags = _lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN
+    monkey_groups = {"REM2D_STEP_GROUPS": "3"}   # three worlds per lane bucket, as large populations have: they merge
     for batches in (pop.compile(2), [pop.compile(2)[-1]]):   # every lane bucket / the widest bucket alone (one world)
         n = sum(len(idx) for _, idx in batches)
         remap = {int(e): k for k, e in enumerate(np.concatenate([np.asarray(idx) for _, idx in batches]))}
@@ -171,7 +172,9 @@ def test_compaction_of_the_survivors_keeps_every_fitness(need_gpu):
         ref_frozen, ref_err = ref_env.frozen.clone(), ref_env.errors().clone()
         ref_env.close()
         env = BatchedModular2D(flags=flags)
+        env.step_groups = int(monkey_groups["REM2D_STEP_GROUPS"])
         env._upload(batches, n)
+        assert len(env.worlds) == 3 * len(batches)
         sizes = [sum(w.n_envs for w, _ in env.worlds)]
         done_steps, alive = 0, n
         while done_steps < 600 and alive > 0:
