@@ -118,29 +118,34 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     const bool run = posIters > 0;
     // Contact slot of body b in iteration n: any tick after its last joint of iteration n - 1 and not after its first
     // joint of iteration n (the contact section of a tick runs before its joint section), i.e. offC + n P with offC in
-    // [lastR + 1 - P, firstR].  The section costs the wavefront the same whether one lane or all are due, so the bodies
-    // are steered to one common phase: the one inside the window of the most touching bodies of the wavefront; a body
-    // whose window misses it keeps the latest tick (its first joint's).  Iteration 0 has no earlier joints: max(offC, 0).
+    // [lastR + 1 - P, firstR].  The section costs the wavefront the same whether one lane or all are due, so (1) the
+    // touching bodies of a creature are steered to one common phase, the one inside the window of the most of them (a
+    // body whose window misses it keeps the latest tick, its first joint's), and (2) -- creatures are independent -- every
+    // creature runs its whole schedule `rot` ticks late so that this phase is phase 0 of the wavefront.  Iteration 0 has no
+    // earlier joints: max(offC, 0).
     const int hiC = anyJoint ? sh.firstR[lane] : 0, loC = anyJoint ? lastB + 1 - P : 1 - P;
-    int offC = hiC;
+    const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
+    int offC = hiC, rot = 0;
     {
         const int Pw = wave_max(P);
-        int best = -1, bestPhase = 0;
-        for (int c = 0; c < Pw; ++c) {
+        int best = 0, bestPhase = 0;
+        for (int c = 0; c < Pw; ++c) { // (per creature: the ballots are masked with its lanes)
             int d = (c - loC) % P;
             d = d < 0 ? d + P : d;
-            const int n = __popcll(__ballot(touching && d <= hiC - loC));
+            const int n = __popcll(__ballot(touching && c < P && d <= hiC - loC) & groupLanes);
             if (n > best) { best = n; bestPhase = c; }
         }
         int d = (bestPhase - loC) % P;
         d = d < 0 ? d + P : d;
         if (d <= hiC - loC) offC = loC + d;
+        rot = best > 0 ? (P - bestPhase) % P : 0;
     }
+    offC += rot;
     int nextC = (run && touching) ? (offC > 0 ? offC : 0) : 0x7fffffff, leftC = posIters, itC = 0;
-    int nextJ = (run && hasJoint) ? jround : 0x7fffffff, leftJ = posIters, itJ = 0;
-    int nextD = run ? maxR : 0x7fffffff, itD = 0;
+    int nextJ = (run && hasJoint) ? jround + rot : 0x7fffffff, leftJ = posIters, itJ = 0;
+    int nextD = run ? maxR + rot : 0x7fffffff, itD = 0;
     unsigned long long failBits = 0ull;
-    const int lastTick = wave_max(run ? maxR + (posIters - 1) * P : -1);
+    const int lastTick = wave_max(run ? maxR + rot + (posIters - 1) * P : -1);
     sh.mbox[0][lane] = px; sh.mbox[1][lane] = py; sh.mbox[2][lane] = ang;
     lds_sync();
 #ifdef REM2D_POS_STAMPS // diagnostic build (tools/pos_stamps_probe.py): where the cycles of a wavefront's tick loop go
