@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--workload", default="lsystem",
                     choices=["lsystem", "chain8", "chain4", "cppn_hardcore", "generation", "single"])
     ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (default: config size)")
-    ap.add_argument("--steps-per-launch", type=int, default=10,
+    ap.add_argument("--steps-per-launch", type=int, default=25,
                     help="env-steps per C-ABI step call (one call = that many kernel sequences queued on the stream)")
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
