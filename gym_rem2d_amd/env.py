@@ -50,6 +50,12 @@ class WallOfDeath:
         self.position += self.speed
 
 
+def _uniform(m):
+    """Every creature of the batch has the same tree and solver schedule (fixed-morphology population)."""
+    n, K = m.n_envs, m.lanes
+    return all(bool((m.arrays[k].reshape(n, K) == m.arrays[k][:K]).all()) for k in ("shape", "parent", "jround"))
+
+
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
     BIG_POPULATION = 100000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
@@ -129,22 +135,28 @@ class BatchedModular2D:
         self._tile_shape_used = None
         self.n_envs = n_envs
         self.streams = []
-        # Step groups: with continuous physics every step ends in the TOI kernels, a long tail of a few busy
-        # wavefronts.  Two independent halves of the population on two streams let one half's TOI tail run
-        # under the other half's step kernel.  (Creatures are independent, so any split is legal.)
-        # The tail grows with the bodies per creature and is short for small uniform creatures (measured:
-        # 65 536 8-module chains lose 5 % with two groups, mixed L-system / 32-lane populations gain 30-40 % with two or three).
+        # Step groups: a step is a chain of four launches, each as long as its slowest wavefront; independent parts of the
+        # population on their own streams let one part's tail run under another part's kernels.  (Creatures are
+        # independent, so any split is legal.)  What counts is the number of 64-lane blocks: below ~3 000 the chip is not
+        # full anyway (4 096 4-module chains: 23.0 M env-steps/s with one group, 20.3 M with two), from ~6 000 on three
+        # groups pay (65 536 L-system creatures, 7 790 blocks: 39 M vs 26 M; 65 536 8-module chains, 8 192 blocks: 136 M
+        # vs 121 M).  Three at most: a fourth group stream was measured to lose 15-30 % whatever the hardware queue count.
         groups = self.step_groups
+        blocks = sum(m.n_envs * m.lanes for m, _ in batches) / 64.0
         if groups <= 0:
-            big = len(batches) > 1 or max(m.lanes for m, _ in batches) >= 16
-            # three at most: with the caller's stream that makes four, the number of hardware queues HIP maps
-            # streams onto by default -- a fourth group stream was measured to serialise (20 M instead of 29 M)
             groups = 1
-            if (self.flags & _lib.FLAG_CONTINUOUS) and big:
-                groups = 3 if n_envs >= 49152 else (2 if n_envs >= 32768 else 1)
+            if self.flags & _lib.FLAG_CONTINUOUS:
+                groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
+        # Tile shape of the velocity kernel: 64-lane tiles up to ~100 000 creatures, 256-lane tiles beyond (see __init__).
+        # Fixed-morphology populations (every creature the same tree: the north-star's "8-module creatures") are the
+        # exception: all creatures of a tile need the same slots per iteration, so a bigger tile costs no more per
+        # iteration and halves the wavefronts -- 128-lane tiles: 170 M instead of 136 M env-steps/s for 65 536 8-module
+        # chains -- once the 64-lane tiles of a step group would no longer fit the chip at once.
         shape = self.tile_shape
         if shape is None and "REM2D_TILE_SHAPE" not in os.environ:
             shape = 0 if n_envs >= self.BIG_POPULATION else 3
+            if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
+                shape = 1
         self._tile_shape_used = shape
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
