@@ -144,9 +144,7 @@ class BatchedModular2D:
         groups = self.step_groups
         blocks = sum(m.n_envs * m.lanes for m, _ in batches) / 64.0
         if groups <= 0:
-            groups = 1
-            if self.flags & _lib.FLAG_CONTINUOUS:
-                groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
+            groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)   # (discrete physics too: 45.3 vs 35.5 M)
         # Tile shape of the velocity kernel: 64-lane tiles up to ~100 000 creatures, 256-lane tiles beyond (see __init__).
         # Fixed-morphology populations (every creature the same tree: the north-star's "8-module creatures") are the
         # exception: all creatures of a tile need the same slots per iteration, so a bigger tile costs no more per
