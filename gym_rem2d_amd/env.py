@@ -137,14 +137,21 @@ class BatchedModular2D:
         self.streams = []
         # Step groups: a step is a chain of four launches, each as long as its slowest wavefront; independent parts of the
         # population on their own streams let one part's tail run under another part's kernels.  (Creatures are
-        # independent, so any split is legal.)  What counts is the number of 64-lane blocks: below ~3 000 the chip is not
-        # full anyway (4 096 4-module chains: 23.0 M env-steps/s with one group, 20.3 M with two), from ~6 000 on three
-        # groups pay (65 536 L-system creatures, 7 790 blocks: 39 M vs 26 M; 65 536 8-module chains, 8 192 blocks: 136 M
-        # vs 121 M).  Three at most: a fourth group stream was measured to lose 15-30 % whatever the hardware queue count.
+        # independent, so any split is legal.)  What counts is the number of 64-lane blocks and how long a step is: below
+        # ~3 000 blocks the chip is not full anyway (4 096 4-module chains: 23.0 M env-steps/s with one group, 20.3 M with
+        # two); mixed or wide-creature populations, whose steps take more than a millisecond, gain up to four groups
+        # (65 536 L-system creatures, 7 790 blocks: 26 / 36 / 39 / 40 M with 1 / 2 / 3 / 4; CPPN creatures on the
+        # hardcore terrain 38.7 / 43.2 / 44.3 M with 2 / 3 / 4); small uniform creatures, whose steps are short, three
+        # (65 536 8-module chains, 8 192 blocks: 121 / 160 / 171 / 135 M with 1 / 2 / 3 / 4).  Never more than four streams
+        # in all, the caller's included (see group_streams below).
         groups = self.step_groups
         blocks = sum(m.n_envs * m.lanes for m, _ in batches) / 64.0
         if groups <= 0:
-            groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)   # (discrete physics too: 45.3 vs 35.5 M)
+            long_steps = len(batches) > 1 or max(m.lanes for m, _ in batches) >= 16
+            if long_steps:
+                groups = 4 if blocks >= 3072 else 1
+            else:
+                groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
         # Tile shape of the velocity kernel: 64-lane tiles up to ~100 000 creatures, 256-lane tiles beyond (see __init__).
         # Fixed-morphology populations (every creature the same tree: the north-star's "8-module creatures") are the
         # exception: all creatures of a tile need the same slots per iteration, so a bigger tile costs no more per
@@ -177,7 +184,9 @@ class BatchedModular2D:
                 self.streams.append(torch.cuda.Stream(device=w.device))
         self.groups = [g for g in self.groups if g]
         dev = self.worlds[0][0].device
-        self.group_streams = [torch.cuda.Stream(device=dev) for _ in self.groups] if len(self.groups) > 1 else [None]
+        # the first group runs on the caller's stream: four streams in all is what the device overlaps well (a fifth costs
+        # 5-25 %: 4 groups on 4 new streams 36.7 M, on the caller's + 3 new ones 40.2 M env-steps/s for config 3)
+        self.group_streams = [None] + [torch.cuda.Stream(device=dev) for _ in self.groups[1:]]
         self._reward = torch.zeros(n_envs, dtype=torch.float32, device=dev)
         self._done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
         self._fitness = torch.zeros(n_envs, dtype=torch.float64, device=dev)
@@ -215,12 +224,16 @@ class BatchedModular2D:
             # all lane buckets of a group in one grid per kernel (rem2d_worlds_step): the dispatcher packs the
             # small buckets next to the big one; on separate streams they mostly ran one after the other
             cur = torch.cuda.current_stream(self.worlds[0][0].device)
-            for g, st in zip(self.groups, self.group_streams):
+            for st in self.group_streams:
+                if st is not None:
+                    st.wait_stream(cur)
+            order = sorted(range(len(self.groups)), key=lambda k: self.group_streams[k] is None)  # the caller's stream last
+            for k in order:
+                g, st = self.groups[k], self.group_streams[k]
                 handles = (C.c_void_p * len(g))(*[self.worlds[i][0].h for i in g])
                 if st is None:
                     _lib.check(_lib.lib().rem2d_worlds_step(handles, len(g), int(n_steps), self.worlds[g[0]][0]._stream()))
                 else:
-                    st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         _lib.check(_lib.lib().rem2d_worlds_step(handles, len(g), int(n_steps),
                                                                 self.worlds[g[0]][0]._stream()))
@@ -311,7 +324,7 @@ class BatchedModular2D:
             if sum(self.worlds[i][0].n_envs for i in active) < 16384 and len(active) <= _lib.MAX_WORLDS_PER_STEP:
                 groups = [active] if active else []   # too few creatures for step groups to pay: one launch sequence
             self.groups = groups
-            self.group_streams = [torch.cuda.Stream(device=self._reward.device) for _ in groups] if len(groups) > 1 else [None]
+            self.group_streams = [None] + [torch.cuda.Stream(device=self._reward.device) for _ in groups[1:]]
         return alive_total
 
     @property
