@@ -149,7 +149,7 @@ class BatchedModular2D:
         if groups <= 0:
             long_steps = len(batches) > 1 or max(m.lanes for m, _ in batches) >= 16
             if long_steps:
-                groups = 4 if blocks >= 3072 else 1
+                groups = 4 if blocks >= 512 else 1   # (8 192 / 16 384 / 24 576 L-system creatures: +13 / +11 / +15 % over one)
             else:
                 groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
         # Tile shape of the velocity kernel: 64-lane tiles up to ~100 000 creatures, 256-lane tiles beyond (see __init__).
