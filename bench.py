@@ -82,8 +82,9 @@ def valu_issue(n_groups):
         return None
     per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
                     if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi")))
-    return {"wave_instructions_per_env_step": per_group * 3, "peak_wave_instructions_per_s": 860e9,
-            "source": "profiles/r02_b_sq_counters.json (3 step groups), profiles/r02_b_ubench_valu_latency.txt"}
+    return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
+            "source": "profiles/r02_b_sq_counters.json (per launch of one of the %d step groups of this command), "
+                      "profiles/r02_b_ubench_valu_latency.txt" % n_groups}
 
 
 def build_population(workload, n_envs, rank):

@@ -16,7 +16,7 @@ timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $CMD > /dev/null 2> $OUT/write.err
 timeout 420 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -- python3 bench.py --steps 10 --warmup 2 --settle 80 --no-cpu-baseline > /dev/null 2> $OUT/sq.err
 python3 tools/collect_profiles.py stats $OUT/stats $OUT/${TAG}_lsystem65536_kernel_stats.csv
-python3 tools/collect_profiles.py trace $OUT/stats $OUT/${TAG}_kernel_trace_timed_region.json 180 "python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+python3 tools/collect_profiles.py trace $OUT/stats $OUT/${TAG}_kernel_trace_timed_region.json 240 "python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline"   # 60 steps x 4 step groups
 python3 tools/collect_profiles.py pmc $OUT/fetch $OUT/write $OUT/${TAG}_pmc_traffic.json "python3 $CMD"
 python3 tools/collect_profiles.py sq $OUT/sq $OUT/${TAG}_sq_counters.json "python3 bench.py --steps 10 --warmup 2 --settle 80 --no-cpu-baseline"
 # the raw traces are large: keep the summaries only
