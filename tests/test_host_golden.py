@@ -276,3 +276,24 @@ def test_gym_make_registration_and_time_limit():
     tl.reset()
     outs = [tl.step(None) for _ in range(3)]
     assert [o[2] for o in outs] == [0, 0, True] and outs[2][3] == {"TimeLimit.truncated": True} and outs[0][3] == 0
+
+
+def test_morphology_concat_take_and_uniform_population_detection():
+    """Host helpers behind BatchedModular2D.compact and the launch-shape rules: concat is the inverse of take, and a
+    fixed-morphology population (every creature the same tree and schedule) is told from a mixed one."""
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    from gym_rem2d_amd.env import _uniform
+    specs = synthetic.lsystem_specs(range(24))
+    m = Morphology.from_specs(specs, 16)
+    a, b = m.take(np.arange(0, 10)), m.take(np.arange(10, 24))
+    back = Morphology.concat([a, b])
+    assert back.n_envs == m.n_envs and back.lanes == m.lanes
+    for k in m.arrays:
+        assert np.array_equal(back.arrays[k], m.arrays[k]), k
+    assert np.array_equal(back.n_bodies, m.n_bodies)
+    with pytest.raises(ValueError):
+        Morphology.concat([a, Morphology.from_specs(specs[:2], 32)])
+    assert not _uniform(m)
+    assert _uniform(synthetic.chain_population(50, 8, "left"))
+    assert _uniform(Morphology.replicate(specs[3], 7, 16))
