@@ -58,7 +58,7 @@ def _uniform(m):
 
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
-    BIG_POPULATION = 100000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
+    BIG_POPULATION = 160000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
@@ -77,9 +77,9 @@ class BatchedModular2D:
         self.merged_launch = os.environ.get("REM2D_MERGED_LAUNCH", "1") != "0"
         self.step_groups = int(os.environ.get("REM2D_STEP_GROUPS", "0"))  # 0 = automatic
         # launch shape of the velocity kernel (rem2d_world_set_tile_shape): None = automatic, unless REM2D_TILE_SHAPE
-        # fixes the process default.  Up to ~100 000 creatures a step is bound by its chain of stragglers and the
+        # fixes the process default.  Up to ~150 000 creatures a step is bound by its chain of stragglers and the
         # 64-lane tiles (4 wavefronts per SIMD) win; beyond that the chip's instruction issue saturates and the 256-lane
-        # tiles (2.4x fewer wave-instructions) do: 51.7 vs 46.5 M env-steps/s at 131 072 creatures.
+        # tiles (2.4x fewer wave-instructions) do: 62.1 vs 58.0 M env-steps/s at 196 608 creatures.
         self.tile_shape = None
         self.groups, self.group_streams = [], []
 
@@ -152,7 +152,7 @@ class BatchedModular2D:
                 groups = 4 if blocks >= 512 else 1   # (8 192 / 16 384 / 24 576 L-system creatures: +13 / +11 / +15 % over one)
             else:
                 groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
-        # Tile shape of the velocity kernel: 64-lane tiles up to ~100 000 creatures, 256-lane tiles beyond (see __init__).
+        # Tile shape of the velocity kernel: 64-lane tiles up to ~150 000 creatures, 256-lane tiles beyond (see __init__).
         # Fixed-morphology populations (every creature the same tree: the north-star's "8-module creatures") are the
         # exception: all creatures of a tile need the same slots per iteration, so a bigger tile costs no more per
         # iteration and halves the wavefronts -- 128-lane tiles: 170 M instead of 136 M env-steps/s for 65 536 8-module
