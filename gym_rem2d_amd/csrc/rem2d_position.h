@@ -19,9 +19,13 @@
 // A 60-iteration creature costs 60*period ticks instead of 60*rounds rounds (3x fewer for 16 modules).
 // ---------------------------------------------------------------------------------------------------
 #define POS_RING 8
+struct __attribute__((aligned(16))) PosRec { float x, y, a, pad; }; // one body's position: one 16-byte LDS access
 struct PosShared {
-    float mbox[3][WAVE];
-    float snap[POS_RING][3][WAVE];
+    union {
+        float mbox[3][WAVE];  // (the fused step kernel's velocity mailbox during its velocity iterations)
+        PosRec pos[WAVE];     // the position solver's mailbox
+    };
+    PosRec snap[POS_RING][WAVE];
     int firstR[WAVE], lastR[WAVE];
 };
 // manifold geometry as the position solver reads it (b2PositionSolverManifold): type | count << 8, local normal,
@@ -146,7 +150,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     int nextD = run ? maxR + rot : 0x7fffffff, itD = 0;
     unsigned long long failBits = 0ull;
     const int lastTick = wave_max(run ? maxR + rot + (posIters - 1) * P : -1);
-    sh.mbox[0][lane] = px; sh.mbox[1][lane] = py; sh.mbox[2][lane] = ang;
+    { PosRec r0; r0.x = px; r0.y = py; r0.a = ang; r0.pad = 0.0f; sh.pos[lane] = r0; }
     lds_sync();
 #ifdef REM2D_POS_STAMPS // diagnostic build (tools/pos_stamps_probe.py): where the cycles of a wavefront's tick loop go
     unsigned long long pT0 = __builtin_amdgcn_s_memtime(), pTa = pT0, pC = 0, pJ = 0, pV = 0;
@@ -162,7 +166,8 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
 #endif
         // ---- contact slot: b2ContactSolver::SolvePositionConstraints for this body's manifolds ----
         if (tick == nextC) {
-            float cx = sh.mbox[0][lane], cy = sh.mbox[1][lane], ca = sh.mbox[2][lane];
+            const PosRec mine = sh.pos[lane];
+            float cx = mine.x, cy = mine.y, ca = mine.a;
             float minSeparation = 0.0f;
 #pragma unroll
             for (int t = 0; t < POS_KR; ++t) // the first manifolds of the body: geometry preloaded into registers
@@ -173,10 +178,11 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 pos_solve_manifold(m, mB, iB, radiusB, cx, cy, ca, minSeparation);
             }
             if (!(minSeparation >= -3.0f * B2_LINEAR_SLOP)) failBits |= 1ull << (itC & 63);
-            sh.mbox[0][lane] = cx; sh.mbox[1][lane] = cy; sh.mbox[2][lane] = ca;
+            PosRec out; out.x = cx; out.y = cy; out.a = ca; out.pad = 0.0f;
+            sh.pos[lane] = out;
             if (!anyJoint) { // the contact slot is this body's last operation of the iteration
                 const int r = itC & (POS_RING - 1);
-                sh.snap[r][0][lane] = cx; sh.snap[r][1][lane] = cy; sh.snap[r][2][lane] = ca;
+                sh.snap[r][lane] = out;
             }
             ++itC;
             nextC = (--leftC > 0) ? offC + itC * P : 0x7fffffff;
@@ -185,10 +191,11 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         POS_STAMP(pC)
         // ---- joint slot: b2RevoluteJoint::SolvePositionConstraints ----
         if (tick == nextJ) {
-            V2 cA = mk(sh.mbox[0][pl], sh.mbox[1][pl]);
-            float aA = sh.mbox[2][pl];
-            V2 cB = mk(sh.mbox[0][lane], sh.mbox[1][lane]);
-            float aB = sh.mbox[2][lane];
+            const PosRec recA = sh.pos[pl], recB = sh.pos[lane];
+            V2 cA = mk(recA.x, recA.y);
+            float aA = recA.a;
+            V2 cB = mk(recB.x, recB.y);
+            float aB = recB.a;
             float angularError = 0.0f, positionError = 0.0f;
             if (limitState != LIM_INACTIVE) {
                 float angle = aB - aA - 0.0f;
@@ -229,12 +236,15 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 cB = vadd(cB, vscale(mB, impulse));
                 aB += iB * vcross(prB, impulse);
             }
-            sh.mbox[0][pl] = cA.x; sh.mbox[1][pl] = cA.y; sh.mbox[2][pl] = aA;
-            sh.mbox[0][lane] = cB.x; sh.mbox[1][lane] = cB.y; sh.mbox[2][lane] = aB;
+            PosRec outA, outB;
+            outA.x = cA.x; outA.y = cA.y; outA.a = aA; outA.pad = 0.0f;
+            outB.x = cB.x; outB.y = cB.y; outB.a = aB; outB.pad = 0.0f;
+            sh.pos[pl] = outA;
+            sh.pos[lane] = outB;
             if (!(positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP)) failBits |= 1ull << (itJ & 63);
             const int r = itJ & (POS_RING - 1);
-            if (isLastA) { sh.snap[r][0][pl] = cA.x; sh.snap[r][1][pl] = cA.y; sh.snap[r][2][pl] = aA; }
-            if (isLastB) { sh.snap[r][0][lane] = cB.x; sh.snap[r][1][lane] = cB.y; sh.snap[r][2][lane] = aB; }
+            if (isLastA) sh.snap[r][pl] = outA;
+            if (isLastB) sh.snap[r][lane] = outB;
             ++itJ;
             nextJ = (--leftJ > 0) ? nextJ + P : 0x7fffffff;
         }
@@ -255,8 +265,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 nextC = nextJ = nextD = 0x7fffffff;
                 if (hasOps) {
                     const int r = itD & (POS_RING - 1);
-                    sh.mbox[0][lane] = sh.snap[r][0][lane]; sh.mbox[1][lane] = sh.snap[r][1][lane];
-                    sh.mbox[2][lane] = sh.snap[r][2][lane];
+                    sh.pos[lane] = sh.snap[r][lane];
                     restored = true;
                 }
             } else {
@@ -276,7 +285,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         atomicAdd(&S.toiWork[8], pJsec); atomicAdd(&S.toiWork[9], 1); atomicMax(&S.toiWork[10], (int)(all >> 6));
     }
 #endif
-    px = sh.mbox[0][lane]; py = sh.mbox[1][lane]; ang = sh.mbox[2][lane];
+    { const PosRec fin = sh.pos[lane]; px = fin.x; py = fin.y; ang = fin.a; }
 }
 
 #endif
