@@ -166,19 +166,30 @@ class BatchedModular2D:
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
-            cuts = [morph.n_envs * g // groups for g in range(groups + 1)] if morph.n_envs >= 4 * groups else [0, morph.n_envs]
+            # which creatures go to which group: wavefront-sized runs of the (schedule-sorted) batch are dealt round-robin,
+            # so that every group gets the same mix of simple and complex creatures and the groups reach the join at the
+            # end of a step call together (contiguous parts, REM2D_GROUP_SPLIT=cut: 40.2 instead of 40.6 M on config 3)
+            if morph.n_envs < 4 * groups:
+                members = [np.arange(morph.n_envs)]
+            elif os.environ.get("REM2D_GROUP_SPLIT") != "cut":
+                run = max(1, 64 // morph.lanes)
+                which = (np.arange(morph.n_envs) // run) % groups
+                members = [np.nonzero(which == g)[0] for g in range(groups)]
+            else:
+                cuts = [morph.n_envs * g // groups for g in range(groups + 1)]
+                members = [np.arange(cuts[g], cuts[g + 1]) for g in range(groups)]
             pieces = []
-            for g in range(len(cuts) - 1):   # one world addresses its lanes with 32-bit offsets: <= MAX_WORLD_LANES
+            for g, mem in enumerate(members):   # one world addresses its lanes with 32-bit offsets: <= MAX_WORLD_LANES
                 per = max(1, self.MAX_WORLD_LANES // morph.lanes)
-                for lo in range(cuts[g], cuts[g + 1], per):
-                    pieces.append((g, lo, min(cuts[g + 1], lo + per)))
-            for g, lo, hi in pieces:
-                part = morph if (lo == 0 and hi == morph.n_envs) else morph.take(np.arange(lo, hi))
+                for lo in range(0, len(mem), per):
+                    pieces.append((g, mem[lo:lo + per]))
+            for g, mem in pieces:
+                part = morph if len(mem) == morph.n_envs else morph.take(mem)
                 w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device)
                 w.set_terrain(self._terrain())
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
-                self.worlds.append((w, torch.as_tensor(idx[lo:hi], dtype=torch.long, device=w.device)))
+                self.worlds.append((w, torch.as_tensor(idx[mem], dtype=torch.long, device=w.device)))
                 self._world_morph.append(part)
                 # fallback path (REM2D_MERGED_LAUNCH=0): one HIP stream per world
                 self.streams.append(torch.cuda.Stream(device=w.device))
