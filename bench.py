@@ -5,8 +5,13 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launc
 torch.distributed.run, one rank per GPU (RCCL) -- or, started bare, it launches those ranks
 itself as a child process (launch_ranks).  One "step" = one Modular2D.step of every
 creature of the batch (controller + PID + world.Step(1/50, 180, 60) + reward/done).  Rank 0
-prints ONE JSON line.  Weak scaling: every rank steps its own 65 536 creatures; the only
-collective is one all-gather of fp32 fitness at the end of the timed region.
+prints ONE JSON line.  `--scaling weak` (default): every rank steps its own 65 536 creatures; `--scaling strong`:
+BASELINE.json's 65 536 creatures are split over the ranks.  Either way the only collective is one all-gather of fp64
+fitness at the end of each timed block.  The K steps are timed as a BLOCK (barrier + synchronize on both sides, max over
+ranks); blocks are repeated until the timed region is >= --min-time seconds (default 1 s) and the MEDIAN block is
+reported (`config.blocks_ms` lists every block), so that a cold first block (fresh process on a fresh box) does not
+decide the figure.  Kernel-exact timing (HIP events) happens in a pass of its own AFTER the timed region; the secondary
+workloads (north_star's 8-module creatures, config 4) are measured in the same process and reported under `secondary`.
 
 Workloads (BASELINE.json configs), all synthetic:
   lsystem  (default, the 65 536-creature config the metric is quoted on): random L-system
@@ -70,6 +75,21 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
+def pmc_traffic_all():
+    """HBM bytes of every kernel of one env-step sequence (per launch of one step group), from the same PMC passes."""
+    for name in ("r03_pmc_traffic.json", "r02_b_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:  # noqa: BLE001
+            continue
+        ks = {k.split("<")[0].split("(")[0]: float(v["hbm_bytes_per_launch"]) for k, v in d["kernels"].items()
+              if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi"))}
+        return {"bytes_per_launch_sequence": sum(ks.values()), "by_kernel": ks, "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def valu_issue(n_groups):
     """VALU wave-instructions per env-step of the default population from the committed SQ-counter pass
     (profiles/r02_b_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
@@ -87,7 +107,7 @@ def valu_issue(n_groups):
                       "profiles/r02_b_ubench_valu_latency.txt" % n_groups}
 
 
-def build_population(workload, n_envs, rank):
+def build_population(workload, n_envs, first):
     """Host-side synthetic input, built BEFORE the GPU is initialised (uses a fork pool)."""
     from gym_rem2d_amd import synthetic
     from gym_rem2d_amd.compiler import Morphology, lanes_for
@@ -100,11 +120,11 @@ def build_population(workload, n_envs, rank):
     import multiprocessing as mp
     import pickle
     import tempfile
-    seeds = np.arange(rank * n_envs, (rank + 1) * n_envs)
+    seeds = np.arange(first, first + n_envs)
     # The specs are cached on disk: a later run (in particular one under rocprofv3 --pmc, whose preloaded library
     # has initialised the GPU before python starts -- forking a worker pool from such a process hangs) loads them
     # instead of forking.
-    cache = os.path.join(tempfile.gettempdir(), "rem2d_bench_%s_%d_%d.pkl" % (workload, n_envs, rank))
+    cache = os.path.join(tempfile.gettempdir(), "rem2d_bench_%s_%d_%d.pkl" % (workload, n_envs, first))
     parts = None
     if os.path.exists(cache):
         try:
@@ -154,18 +174,45 @@ def _repack(m, lanes):
     return out
 
 
-def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=25.0):
+def host_cores():
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max, v1 cfs)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
     """The oracle (C restatement of the reference's Box2D path, OpenMP over creatures) on a bounded sample of the same
-    workload, over the SAME step window the GPU leg times: steps [settle, settle + window) after reset.  The oracle
-    has no "continue" call, so the window is the difference of two runs from reset (it is deterministic).  All lane
-    buckets go into ONE batch_run (re-laid out on the widest lane count) so that every host thread stays busy."""
+    workload, over the SAME step window the GPU leg times: steps [settle, settle + window) after reset, as ONE continuous
+    wall-clock window (rem2d_oracle_batch_window: the settle steps are untimed, the worlds are kept).  All lane buckets
+    go into one batch (re-laid out on the widest lane count) so that every host thread stays busy."""
     from oracle import oracle as O
     O.build()
     xs, ys, polys = terrain.f32()
     ot = O.Terrain(xs, ys, polys if len(polys) else None, terrain.friction)
-    cores = os.cpu_count() or 1
+    cores, quota = host_cores()
     total = sum(m.n_envs for m in morphs)
-    want = min(total, max(256, 32 * cores))            # >= 32 creatures per host thread
+    want = min(total, max(256, 48 * cores), 8192)      # >= 48 creatures per host thread (creature costs vary a lot)
     lanes = max(m.lanes for m in morphs)
     parts = []
     for m in morphs:
@@ -176,19 +223,7 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=25.0):
         if k not in ("n_envs", "lanes"):
             sample[k] = np.concatenate([p[k] for p in parts])
     n = sample["n_envs"]
-
-    def timed(steps, threads, sub=None):
-        d = sample if sub is None else sub
-        t0 = time.perf_counter()
-        O.batch_run(ot, d, steps, n_threads=threads, flags=flags)
-        return time.perf_counter() - t0
-    t_settle = timed(settle, cores)
-    # size the window so that the whole leg stays within the budget
-    rate_guess = n * max(1, settle) / max(t_settle, 1e-3)
-    window = int(max(20, min(max(window, 100), (budget_s * 0.5 * rate_guess / n - settle))))
-    t_full = timed(settle + window, cores)
-    all_threads = n * window / max(t_full - t_settle, 1e-6)
-    # one thread: a slice of the sample, same window
+    # one thread first (a slice of the sample): it also sizes the window of the all-thread leg to the budget
     n1 = max(8, min(n, 32))
     idx = np.linspace(0, n - 1, n1).astype(np.int64)
     lanes_idx = (idx[:, None] * lanes + np.arange(lanes)[None, :]).reshape(-1)
@@ -196,16 +231,23 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=25.0):
     for k, v in sample.items():
         if k not in ("n_envs", "lanes"):
             sub[k] = v[lanes_idx]
-    w1 = max(100, min(window, 200))
-    t1a = min(timed(settle, 1, sub) for _ in range(2))
-    t1b = min(timed(settle + w1, 1, sub) for _ in range(2))
-    one_thread = n1 * w1 / max(t1b - t1a, 1e-3)
-    return {"value": all_threads, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "what": "oracle/rem2d_oracle.c (CPU restatement of the reference's Box2D 2.3.x path; pybox2d itself is not installable here)",
+    w1 = max(50, min(window, 200))
+    t1, _ = O.batch_window(ot, sub, settle, w1, n_threads=1, flags=flags)
+    one_thread = n1 * w1 / max(t1, 1e-6)
+    # all threads: window sized so that settle + window stays within the budget at ~cores x the 1-thread rate
+    per_step = n / max(one_thread * cores * 0.7, 1.0)     # seconds per step of the whole sample (estimate)
+    window = int(max(20, min(max(window, 100), budget_s / per_step - settle)))
+    tw, _ = O.batch_window(ot, sample, settle, window, n_threads=cores, flags=flags)
+    all_threads = n * window / max(tw, 1e-6)
+    return {"value": all_threads, "unit": "env-steps/s", "cores": cores, "kind": "port", "is_oracle": True,
+            "cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota,
+            "what": "oracle/rem2d_oracle.c -- this repository's test oracle, a CPU restatement of the reference's Box2D 2.3.x "
+                    "path (pybox2d itself is not installable here), OpenMP over creatures",
             "value_1thread": one_thread,
             "sample": "%d creatures (proportional slice of every lane bucket, one batch on %d lanes), steps [%d, %d) after reset "
-                      "-- the window the GPU leg times; OpenMP over creatures on %d threads; 1-thread figure: %d creatures x %d steps"
-                      % (n, lanes, settle, settle + window, cores, n1, w1)}
+                      "as one continuous timed window of %.2f s (the settle steps untimed) -- the window the GPU leg times; %d "
+                      "threads (affinity mask / cgroup quota); 1-thread figure: %d creatures x %d steps"
+                      % (n, lanes, settle, settle + window, tw, cores, n1, w1)}
 
 
 def launch_ranks(args):
@@ -231,6 +273,46 @@ def launch_ranks(args):
     sys.exit(proc.returncode)
 
 
+METRIC = "env steps/sec (whole node) at 65 536 parallel creatures; 1/2/4/8-GPU scaling"   # BASELINE.json's, verbatim
+
+
+def make_env(morphs, dev, hard, flat, discrete):
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    env = BatchedModular2D(flat=flat, hardcore=hard, seed=4, device=dev, flags=0 if discrete else _lib.FLAG_CONTINUOUS)
+    batches, lo = [], 0
+    for m in morphs:
+        batches.append((m, list(range(lo, lo + m.n_envs))))
+        lo += m.n_envs
+    env._upload(batches, lo)
+    return env
+
+
+def stepper(env, spl):
+    def run(n):
+        left = n
+        while left > 0:
+            k = min(spl, left)
+            env.step(k)
+            left -= k
+    return run
+
+
+def timed_blocks(run_block, steps, min_time, max_blocks, sync, reduce_max):
+    """Repeat [sync, K steps (+ what belongs to a block), sync] until the blocks add up to min_time seconds (at least one,
+    at most max_blocks).  Every block is exactly K steps between a barrier + synchronize on both sides; its time is the
+    max over ranks.  Returns the list of block times in seconds."""
+    blocks = []
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        run_block(steps)
+        sync()
+        blocks.append(reduce_max(time.perf_counter() - t0))
+        if sum(blocks) >= min_time or len(blocks) >= max_blocks:
+            return blocks
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,14 +320,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="lsystem",
                     choices=["lsystem", "chain8", "chain4", "cppn_hardcore", "generation", "single"])
-    ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (default: config size)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank steps its own --envs creatures; strong: --envs creatures in all, split over the ranks")
+    ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (weak) / in all (strong); default: config size")
     ap.add_argument("--steps-per-launch", type=int, default=25,
-                    help="env-steps per C-ABI step call (one call = that many kernel sequences queued on the stream)")
+                    help="env-steps per C-ABI step call (one call = that many kernel sequences queued on the streams)")
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
+    ap.add_argument("--min-time", type=float, default=1.0,
+                    help="repeat the --steps block until the timed region is at least this long (seconds); the median block is reported")
+    ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (chain8, cppn_hardcore) measured after the headline one")
     ap.add_argument("--step-groups", type=int, default=None,
-                    help="independent halves/thirds of the population stepped on separate streams (default: automatic)")
+                    help="independent parts of the population stepped on separate streams (default: automatic)")
+    ap.add_argument("--graph", type=int, default=None, choices=[0, 1], help="replay every step call as a hipGraph (REM2D_GRAPH)")
     ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2, 3],
                     help="3 = tile pipeline pre / rem2d_vel4_kernel / post (the library's default), 0 = fused rem2d_step_multi_kernel")
     ap.add_argument("--discrete", action="store_true",
@@ -260,13 +350,25 @@ def main():
         os.environ["REM2D_STEP_GROUPS"] = str(args.step_groups)
     if args.pipeline is not None:
         os.environ["REM2D_PIPELINE"] = str(args.pipeline)  # read once by librem2d at the first step
+    if args.graph is not None:
+        os.environ["REM2D_GRAPH"] = str(args.graph)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     single = args.workload == "single"
-    n_envs = args.envs or {"chain4": 4096, "generation": 131072, "single": 1}.get(args.workload, 65536)
     generation = args.workload == "generation"
+    n_config = args.envs or {"chain4": 4096, "generation": 131072, "single": 1}.get(args.workload, 65536)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # BASELINE's population cut into contiguous shards: rank r owns creatures [r * ceil(n / W), ...) -- evaluate.shard_range
+        per = -(-n_config // world)
+        first, n_envs = rank * per, max(0, min(n_config, (rank + 1) * per) - rank * per)
+        if n_envs == 0:
+            sys.exit("bench.py: more ranks than creatures")
+    else:
+        first, n_envs = rank * n_config, n_config
+    total = n_config if strong else n_config * world
     if single:
         # config 1 (Demo1_Random_Individual.py:4-36): one direct-encoding individual, random.seed(0), seed-4 terrain, 1000 steps
         from gym_rem2d_amd import synthetic
@@ -277,14 +379,18 @@ def main():
                          "from reset (Demo1_Random_Individual.py path)" % n_envs)
         args.settle = 0
     else:
-        morphs, workload_desc = build_population("lsystem" if generation else args.workload, n_envs, rank)
+        morphs, workload_desc = build_population("lsystem" if generation else args.workload, n_envs, first)
     if generation:
         workload_desc = "one EA generation: whole episodes (evaluate() rule, <= 2500 steps) of " + workload_desc
+    # the secondary workloads' host-side input, also before the GPU is initialised (fork pool)
+    secondary_in = {}
+    if args.workload == "lsystem" and world == 1 and not args.no_secondary and n_envs == 65536 and not args.discrete:
+        for wl in ("chain8", "cppn_hardcore"):
+            secondary_in[wl] = build_population(wl, 65536, 0)
 
     import torch
     import torch.distributed as dist
     from gym_rem2d_amd import make_terrain
-    from gym_rem2d_amd.env import BatchedModular2D
     from gym_rem2d_amd.evaluate import all_gather_fitness
 
     n_dev = torch.cuda.device_count()   # does not initialise the GPU
@@ -298,25 +404,12 @@ def main():
             dist.init_process_group(backend)
     cdev = dev if backend == "nccl" else torch.device("cpu")
 
-    from gym_rem2d_amd import _lib
     hard = args.workload == "cppn_hardcore"
     flat = not hard and not single
-    env = BatchedModular2D(flat=flat, hardcore=hard, seed=4, device=dev,
-                           flags=0 if args.discrete else _lib.FLAG_CONTINUOUS)
-    batches, lo = [], 0
-    for m in morphs:
-        batches.append((m, list(range(lo, lo + m.n_envs))))
-        lo += m.n_envs
-    env._upload(batches, lo)
-
+    env = make_env(morphs, dev, hard, flat, args.discrete)
     spl = max(1, args.steps_per_launch)
-
-    def run(n):
-        left = n
-        while left > 0:
-            k = min(spl, left)
-            env.step(k)
-            left -= k
+    run = stepper(env, spl)
+    per_rank = -(-total // world)       # all_gather_fitness pads every rank's shard to this
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -324,18 +417,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def block(n):
+        run(n)
+        fit = env.fitness
+        if world > 1:
+            all_gather_fitness(fit.to(cdev), per_rank * world)   # the job's only collective
+
     if generation:
         args.settle = args.warmup = 0
     run(args.settle)
     run(args.warmup)
-    for w, _ in env.worlds:          # event pairs are created here, outside the timed region
-        w.enable_timing(True)
-        w.kernel_time_ms()
-        w.step_time_ms()
-    sync()
-    t0 = time.perf_counter()
     if generation:
         from gym_rem2d_amd.evaluate import EPISODE_CAP
+        sync()
+        t0 = time.perf_counter()
         done_steps = 0
         while done_steps < EPISODE_CAP:
             env.step(100)
@@ -343,29 +445,39 @@ def main():
             if bool((env.frozen != 0).all()):
                 break
         args.steps = done_steps
+        fit = env.fitness
+        if world > 1:
+            all_gather_fitness(fit.to(cdev), per_rank * world)
+        sync()
+        blocks = [reduce_max(time.perf_counter() - t0)]
     else:
-        run(args.steps)
-    fit = env.fitness
-    if world > 1:
-        fit = all_gather_fitness(fit.to(cdev), n_envs * world)  # the generation's only collective
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        blocks = timed_blocks(block, args.steps, args.min_time, args.max_blocks, sync, reduce_max)
+    dt = float(np.median(blocks))
+    err = int(env.errors().max())
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, recorded by the library) ----
-    # Every launch covers one step group (all lane buckets of a third of the population in one grid); its time is booked
-    # on the group's first world.
+    # ---- roofline of the dominant kernel: a pass of its own AFTER the timed region, with HIP events recorded by the
+    # library on the launch streams (one more block of K steps of the same population, continuing where the timed
+    # region stopped).  Every launch covers one step group (all lane buckets of that part of the population in one
+    # grid); its time is booked on the group's first world. ----
     pipeline = int(os.environ.get("REM2D_PIPELINE", "3"))
     ms = launches = 0
     ms_step = n_step = 0
-    for w, _ in env.worlds:
-        a, b = w.kernel_time_ms()
-        c, d = w.step_time_ms()
-        w.enable_timing(False)
-        ms, launches, ms_step, n_step = ms + a, launches + b, ms_step + c, n_step + d
+    timing_steps = 0
+    if not generation:
+        firsts = [env.worlds[g[0]][0] for g in env.groups] if env.groups else [env.worlds[0][0]]
+        for w in firsts:          # event pairs are created here; only each group's first world records
+            w.enable_timing(True)
+            w.kernel_time_ms()
+            w.step_time_ms()
+        timing_steps = min(args.steps, 200)
+        sync()
+        run(timing_steps)
+        sync()
+        for w in firsts:
+            a, b = w.kernel_time_ms()
+            c, d = w.step_time_ms()
+            w.enable_timing(False)
+            ms, launches, ms_step, n_step = ms + a, launches + b, ms_step + c, n_step + d
     merged = len(env.worlds) > 1 and env.merged_launch
     n_groups = max(1, len(env.groups))
     kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel",
@@ -374,22 +486,40 @@ def main():
     flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))
     # algorithmic bytes of one launch / its average duration == bytes of all timed launches / their total duration
     avg_ms = ms / max(1, launches)
-    achieved = bytes_per_step * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    achieved_step = bytes_per_step * args.steps / (ms_step * 1e-3) / 1e9 if ms_step > 0 else None
-    valu = flops_per_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic_bytes, traffic_src = (pmc_traffic(kname) if (args.workload == "lsystem" and not args.discrete and n_envs == 65536)
-                                  else (None, None))
+    achieved = bytes_per_step * timing_steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    achieved_step = bytes_per_step * timing_steps / (ms_step * 1e-3) / 1e9 if ms_step > 0 else None
+    valu = flops_per_step * timing_steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    headline = args.workload == "lsystem" and not args.discrete and n_envs == 65536
+    traffic_bytes, traffic_src = pmc_traffic(kname) if headline else (None, None)
     traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
-    err = int(env.errors().max())
-    issue = valu_issue(n_groups) if traffic_src and pipeline == 3 else None
+    traffic_all = pmc_traffic_all() if headline else None
+    issue = valu_issue(n_groups) if headline and pipeline == 3 else None
     if issue:
         issue["achieved_wave_instructions_per_s"] = issue["wave_instructions_per_env_step"] * args.steps / dt
         issue["frac"] = issue["achieved_wave_instructions_per_s"] / issue["peak_wave_instructions_per_s"]
 
+    # ---- secondary workloads, same process: north_star's "8-module creatures" and config 4 ----
+    secondary = None
+    if secondary_in and rank == 0:
+        secondary = {}
+        env.close()
+        for wl, (m2, desc2) in secondary_in.items():
+            hard2 = wl == "cppn_hardcore"
+            env2 = make_env(m2, dev, hard2, not hard2, False)
+            run2 = stepper(env2, spl)
+            run2(args.settle)
+            run2(20)
+            b2 = timed_blocks(run2, 100, 0.5, 50, sync, reduce_max)
+            d2 = float(np.median(b2))
+            secondary[wl] = {"value": 65536 * 100 / d2, "unit": "env-steps/s", "ms_per_step": d2 / 100 * 1e3,
+                             "workload": desc2, "steps_per_block": 100, "blocks_ms": [round(x * 1e3, 3) for x in b2],
+                             "timed_region_s": float(sum(b2)), "step_groups": max(1, len(env2.groups)),
+                             "tile_shape": env2._tile_shape_used, "solver_errors": int(env2.errors().max())}
+            env2.close()
+
     if rank == 0:
-        total = n_envs * world
         out = {
-            "metric": "env steps/sec (whole node) at %s parallel creatures" % format(total, ",").replace(",", " "),
+            "metric": METRIC,
             "value": total * args.steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -397,11 +527,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload_desc, "envs_per_gpu": n_envs,
+            "config": {"workload": workload_desc, "creatures_total": total, "envs_per_gpu": n_envs,
                        "pipeline": {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
                                     1: "split (4-wave velocity kernel)", 2: "split (vel3)"}[pipeline],
                        "kernel_launches_per_env_step_per_group": (4 if not args.discrete else 3) if pipeline == 3 else None,
@@ -410,14 +540,20 @@ def main():
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,
                        "continuous_physics": not args.discrete,
                        "parallelism": "population sharded over %d rank(s), one per GPU, no per-step collective; one fp64 "
-                                      "fitness all-gather (%s)" % (world, backend if world > 1 else "none at 1 rank"),
+                                      "fitness all-gather per block (%s)" % (world, backend if world > 1 else "none at 1 rank"),
                        "ranks_share_one_gpu": bool(world > 1 and n_dev < world),
-                       "merged_launch": bool(merged), "step_groups": n_groups,
-                       "timed_region_s": dt,
+                       "merged_launch": bool(merged), "step_groups": n_groups, "hip_graph": bool(env.use_graph),
+                       # every block = exactly `steps` env-steps between barrier + synchronize; value = median block
+                       "blocks": len(blocks), "blocks_ms": [round(x * 1e3, 3) for x in blocks],
+                       "block_ms_median": dt * 1e3, "block_ms_first": blocks[0] * 1e3, "block_ms_min": min(blocks) * 1e3,
+                       "timed_region_s": float(sum(blocks)),
                        "solver_errors": err},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         # HBM bytes of ALL kernels of an env-step sequence of one step group (pre .. toi_heavy), same PMC passes
+                         "traffic_all_kernels": traffic_all,
                          "kernel": kname, "avg_launch_ms": avg_ms, "launches": launches,
+                         "timing_pass": "%d env-steps after the timed region, HIP events on the launch streams" % timing_steps,
                          # the same algorithmic bytes over the device time of ALL kernels of an env-step (pre .. toi_heavy)
                          "achieved_all_step_kernels": achieved_step,
                          "avg_step_sequence_ms": (ms_step / n_step) if n_step else None,
@@ -430,11 +566,11 @@ def main():
                          "valu_issue": issue,
                          "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d), all of them "
                                  "charged to the dominant kernel; the path is bound by the per-wavefront issue interval over "
-                                 "the 180+60 Gauss-Seidel sweeps (FP32 VALU; valu_issue.frac of the measured issue "
+                                 "the 180+60 Gauss-Seidel sweeps (FP32 VALU; valu_issue.frac of the issue "
                                  "peak), not by HBM"},
         }
-        if dt < 0.5:
-            out["config"]["note"] = "timed region shorter than 0.5 s: expect a few per cent of run-to-run noise"
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:
             from gym_rem2d_amd import make_terrain as _mt
             window = args.steps if not generation else 200

@@ -9,6 +9,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("REM2D_LIB_PATH") or os.path.join(_HERE, "librem2d.so")   # override: A/B builds on the GPU box
+# the same source built with -DREM2D_WIDE (32 pair slots / 12 solver slots per body): where the creatures that overflowed the
+# default build's slots are re-evaluated (evaluate.run_episode) -- Box2D itself has no cap (Modular2DEnv.py:634)
+WIDE_LIB_PATH = os.environ.get("REM2D_WIDE_LIB_PATH") or os.path.join(_HERE, "librem2d_wide.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "rem2d.hip")
 
 FLAG_CONTINUOUS = 1
@@ -18,6 +21,8 @@ FLAG_SKIP_FROZEN = 8
 
 CONTACT_SLOTS = 24
 MAX_WORLDS_PER_STEP = 8
+MAX_STEP_GROUPS = 16
+STEP_GRAPH = 1
 SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
@@ -73,46 +78,69 @@ class NetworkGenomes(C.Structure):
                                              "ctl_max_offset", "ctl_max_freq")])
 
 
+class StepGroup(C.Structure):
+    """rem2d_step_group (include/rem2d.h)."""
+    _fields_ = [("worlds", C.POINTER(C.c_void_p)), ("n_worlds", C.c_int32), ("stream", C.c_void_p)]
+
+
 class Rem2dError(RuntimeError):
     pass
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so (hipcc cross-compiles
-    without a GPU).  -ffp-contract=off keeps every binary32 operation separately rounded."""
+    """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so and (-DREM2D_WIDE) librem2d_wide.so (hipcc
+    cross-compiles without a GPU; the two compile side by side).  -ffp-contract=off keeps every binary32 operation
+    separately rounded."""
     csrc = os.path.dirname(SRC_PATH)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "rem2d.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    # -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov)
-    # than it saves here; without it the step kernel fits 238 VGPRs with no spills (+11..14 % env-steps/s)
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
-           "-shared",
-           "-I" + os.path.join(_ROOT, "include"), SRC_PATH, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    newest = max(os.path.getmtime(d) for d in deps)
+    procs = []
+    for path, extra in ((LIB_PATH, []), (WIDE_LIB_PATH, ["-DREM2D_WIDE=1"])):
+        if not force and os.path.exists(path) and os.path.getmtime(path) >= newest:
+            continue
+        # -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov)
+        # than it saves here; without it the step kernel fits 238 VGPRs with no spills (+11..14 % env-steps/s)
+        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
+               "-shared"] + extra + ["-I" + os.path.join(_ROOT, "include"), SRC_PATH, "-o", path]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return LIB_PATH
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def capacity(wide=False):
+    """(REM2D_CONTACT_SLOTS, REM2D_SOLVER_SLOTS) of the default / the wide build."""
+    a, b = C.c_int32(), C.c_int32()
+    check(lib(wide).rem2d_capacity(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def lib(wide=False):
     global _lib
-    if _lib is not None:
+    if not wide and _lib is not None:
         return _lib
+    if wide and True in _libs:
+        return _libs[True]
+    path = WIDE_LIB_PATH if wide else LIB_PATH
     # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
     # Import torch first so that librem2d.so binds to the runtime torch initialises -- two runtimes
     # in one process fail with "no ROCm-capable device is detected".
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise Rem2dError(
             "gym_rem2d_amd: %s is missing -- the HIP extension is required (there is no CPU fallback). "
-            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % path)
+    L = C.CDLL(path)
     L.rem2d_abi_version.restype = C.c_int
     L.rem2d_last_error.restype = C.c_char_p
+    L.rem2d_capacity.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rem2d_state_bytes.restype = C.c_size_t
     L.rem2d_state_bytes.argtypes = [C.POINTER(WorldCfg)]
     L.rem2d_padded_envs.restype = C.c_int32
@@ -134,6 +162,9 @@ def lib():
     L.rem2d_worlds_step.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]
     L.rem2d_worlds_step_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_void_p]
+    L.rem2d_groups_step.argtypes = [C.POINTER(StepGroup), C.c_int32, C.c_int32, C.c_void_p, C.c_uint32]
+    L.rem2d_groups_step_ex.argtypes = [C.POINTER(StepGroup), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_uint32]
     L.rem2d_compile_lsystem.argtypes = [C.POINTER(LsystemGenomes), C.c_int32, C.c_int32, C.c_double, C.c_int32,
                                         C.POINTER(Morph), C.c_void_p, C.c_int32]
     L.rem2d_compile_trees.argtypes = [C.POINTER(TreeBatch), C.c_double, C.c_int32, C.POINTER(Morph), C.c_void_p, C.c_int32]
@@ -145,9 +176,12 @@ def lib():
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 5:
-        raise Rem2dError("librem2d.so ABI version mismatch")
-    _lib = L
+    if L.rem2d_abi_version() != 6:
+        raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
+    if wide:
+        _libs[True] = L
+    else:
+        _lib = L
     return L
 
 
@@ -164,6 +198,6 @@ def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_sh
     return out[:n.value + 1].copy()
 
 
-def check(rc):
+def check(rc, wide=False):
     if rc != 0:
-        raise Rem2dError("librem2d: error %d: %s" % (rc, lib().rem2d_last_error().decode()))
+        raise Rem2dError("librem2d: error %d: %s" % (rc, lib(wide).rem2d_last_error().decode()))

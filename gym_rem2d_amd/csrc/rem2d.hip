@@ -40,6 +40,18 @@
 #define KR 3                    // ... of which this many are register resident in the velocity loop
 #define WAVE 64
 #define SCR_WORDS 9 // manifold scratch words per solver slot
+// pair-slot map of a body's touching contacts: 5 bits per solver slot (REM2D_CONTACT_SLOTS <= 32), one or two words
+static_assert(KC <= 32, "pair-slot indices are packed in 5 bits");
+#if REM2D_SOLVER_SLOTS * 5 <= 32
+typedef unsigned slotpack_t;
+#define SP_WORDS 1
+#else
+typedef unsigned long long slotpack_t;
+#define SP_WORDS 2
+static_assert(KT * 5 <= 64, "pair-slot map: at most 12 solver slots");
+#endif
+#define SP_PUT(s, t) ((slotpack_t)(unsigned)(s) << (5 * (t)))
+#define SP_GET(p, t) ((unsigned)((p) >> (5 * (t))) & 0x1fu)
 
 // ---- b2Settings.h constants (same expressions as Box2D so that they fold identically) ----
 #define B2_PI 3.14159265359f
@@ -113,6 +125,8 @@ struct rem2d_world {
     int evUsedStep;
     double accumMsStep;
     int64_t launchesStep;
+    hipEvent_t evFork, evJoin; // fork / join edges of rem2d_groups_step (created on first use)
+    uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
 };
 
 // Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
@@ -134,8 +148,19 @@ static TileShape tile_shape(int id) {
     return shapes[(id == 0 || id == 1) ? id : 3];
 }
 
+static uint32_t __float_as_uint_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
 extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
 extern "C" const char *rem2d_last_error(void) { return g_err.c_str(); }
+extern "C" int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots) {
+    if (contact_slots) *contact_slots = REM2D_CONTACT_SLOTS;
+    if (solver_slots) *solver_slots = REM2D_SOLVER_SLOTS;
+    return REM2D_OK;
+}
 
 static bool cfg_ok(const rem2d_world_cfg *cfg) {
     if (!cfg || cfg->n_envs <= 0) return false;
@@ -151,6 +176,10 @@ extern "C" int32_t rem2d_padded_envs(const rem2d_world_cfg *cfg) {
     return make_layout(cfg).Np;
 }
 
+static uint64_t next_epoch() {
+    static uint64_t e = 0;
+    return ++e;
+}
 static void bind_state(rem2d_world *w) {
     State &S = w->S;
     const Layout &L = w->L;
@@ -193,6 +222,8 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->launchesStep = 0;
     w->accumMs = 0.0;
     w->launches = 0;
+    w->evFork = w->evJoin = nullptr;
+    w->epoch = next_epoch();
     bind_state(w);
     w->S.scr = nullptr;
     hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
@@ -248,6 +279,7 @@ extern "C" int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_
     w->S.outReward = reward_dev;
     w->S.outDone = done_dev;
     w->S.outIndex = index_dev;
+    w->epoch = next_epoch();
     return REM2D_OK;
 }
 
@@ -288,6 +320,7 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
     w->tilesDev = dev;
     w->nTiles = n_tiles;
     w->S.tiles = dev;
+    w->epoch = next_epoch();
     return REM2D_OK;
 }
 
@@ -412,6 +445,8 @@ extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (!w) return REM2D_OK;
     (void)hipSetDevice(w->cfg.device);
     free_timing(w);
+    if (w->evFork) (void)hipEventDestroy(w->evFork);
+    if (w->evJoin) (void)hipEventDestroy(w->evJoin);
     if (w->S.scr) (void)hipFree(w->S.scr);
     if (w->tilesDev) (void)hipFree(w->tilesDev);
     if (w->terrainBuf) (void)hipFree(w->terrainBuf);
@@ -532,6 +567,7 @@ extern "C" int rem2d_world_set_terrain(rem2d_world *w, const float *xs, const fl
     T.invPitch = 1.0f / pitch;
     T.friction = sqrtf(friction * 0.1f); // b2MixFriction(terrain fixture, module fixture friction 0.1)
     w->haveTerrain = true;
+    w->epoch = next_epoch();
     return REM2D_OK;
 }
 
@@ -558,10 +594,21 @@ static int pipeline_mode() {
 }
 
 // The tile pipeline for one or several worlds (lane buckets) in one grid per kernel: pre and post run one body per
-// lane; the velocity iterations run one tile per wavefront (rem2d_vel4.h).
-static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float dt, int vel_iters, int pos_iters, hipStream_t st) {
+// lane; the velocity iterations run one tile per wavefront (rem2d_vel4.h).  TilePlan = the launch arguments of one env-step of
+// one step group (they do not change from step to step); tiles_launch_step enqueues that step's kernels.
+struct TilePlan {
     Batch B;
     Vel4Batch VB;
+    StepArgs A;
+    Vel4Args V;
+    unsigned blocks, tiles;
+    int launchShape;
+    bool continuous;
+    rem2d_world *w0;
+};
+static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float dt, int vel_iters, int pos_iters) {
+    Batch &B = P.B;
+    Vel4Batch &VB = P.VB;
     memset(&B, 0, sizeof(B));
     memset(&VB, 0, sizeof(VB));
     unsigned blocks = 0, tiles = 0;
@@ -587,50 +634,66 @@ static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         VB.tileEnd[i] = tiles;
     }
     B.n = VB.n = n_worlds;
-    rem2d_world *w0 = ws[0];
+    P.blocks = blocks;
+    P.tiles = tiles;
+    P.w0 = ws[0];
     // worlds planned for different tile shapes in one grid: the largest shape runs the smaller ones' tiles as well
     // (a tile within 64 joints fits any shape; one within 64 joints per phase pair fits the four-set shape)
-    int launchShape = 3;
+    P.launchShape = 3;
     for (int i = 0; i < n_worlds; ++i) {
         const int id = ws[i]->tileShape;
-        if (id == 0 || (id == 1 && launchShape == 3)) launchShape = id;
+        if (id == 0 || (id == 1 && P.launchShape == 3)) P.launchShape = id;
     }
-    const bool continuous = (w0->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
-    StepArgs A;
-    A.nSteps = 1;
-    A.dt = dt;
-    A.velIters = vel_iters;
-    A.posIters = pos_iters;
-    A.heavyPerWave = heavy_per_wave();
-    A.defer = continuous ? 2 : 0; // 2: post runs the TOI scan itself (the fused kernel's path keeps 1 = separate scan kernel)
-    Vel4Args V;
-    V.velIters = vel_iters;
-    V.dt = dt;
+    P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
+    P.A.nSteps = 1;
+    P.A.dt = dt;
+    P.A.velIters = vel_iters;
+    P.A.posIters = pos_iters;
+    P.A.heavyPerWave = heavy_per_wave();
+    P.A.defer = P.continuous ? 2 : 0; // 2: post runs the TOI scan itself (the fused kernel's path keeps 1 = separate scan kernel)
+    P.V.velIters = vel_iters;
+    P.V.dt = dt;
     static const int v4dbg = getenv("REM2D_V4_DBG") ? atoi(getenv("REM2D_V4_DBG")) : 0;
-    V.dbg = v4dbg;
-    const dim3 grid(blocks), block(WAVE);
-    for (int l = 0; l < n_steps; ++l) {
-        const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
-                               hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
-        hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, B, A);
-        // dominant kernel: its own begin / end timestamps (hipExtLaunchKernelGGL's start / stop events bracket exactly
-        // the kernel, which is what rocprofv3 --kernel-trace reports; events recorded on the stream around the launch
-        // also count the dispatch gaps, 50-100 us when three step groups share the command processor)
-        const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
-        hipEvent_t e0 = timed ? w0->evPool[w0->evUsed].first : nullptr, e1 = timed ? w0->evPool[w0->evUsed].second : nullptr;
-        switch (launchShape) {
-        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
-        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
-        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(tiles), block, 0, st, e0, e1, 0, VB, V); break;
+    P.V.dbg = v4dbg;
+}
+// one env-step of one step group.  With timing on (rem2d_world_enable_timing; never inside a region whose wall time is
+// being measured -- bench.py times kernels in a pass of its own) the dominant kernel gets its own begin / end timestamps
+// (hipExtLaunchKernelGGL's start / stop events bracket exactly the kernel, which is what rocprofv3 --kernel-trace
+// reports; events recorded on the stream around the launch also count the dispatch gaps) and the whole sequence a pair
+// of stream events.
+static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
+    rem2d_world *w0 = P.w0;
+    const dim3 grid(P.blocks), block(WAVE);
+    const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
+                           hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
+    hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, P.B, P.A);
+    const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
+    if (timed) {
+        hipEvent_t e0 = w0->evPool[w0->evUsed].first, e1 = w0->evPool[w0->evUsed].second;
+        switch (P.launchShape) {
+        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
         }
-        if (timed) w0->evUsed += 1;
-        hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, B, A);
-        if (continuous) hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, B, A);
-        if (timedStep) {
-            (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
-            w0->evUsedStep += 1;
+        w0->evUsed += 1;
+    } else {
+        switch (P.launchShape) {
+        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
         }
     }
+    hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, P.B, P.A);
+    if (P.continuous) hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, P.B, P.A);
+    if (timedStep) {
+        (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
+        w0->evUsedStep += 1;
+    }
+}
+static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float dt, int vel_iters, int pos_iters, hipStream_t st) {
+    TilePlan P;
+    tiles_plan(P, ws, n_worlds, dt, vel_iters, pos_iters);
+    for (int l = 0; l < n_steps; ++l) tiles_launch_step(P, st);
     HIP_TRY(hipGetLastError());
     return REM2D_OK;
 }
@@ -711,6 +774,146 @@ extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32
 extern "C" int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream) {
     // Modular2DEnv.py:634  self.world.Step(1.0/FPS, 6*30, 2*30)
     return rem2d_world_step_ex(w, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream);
+}
+
+// ---- all step groups of a population in one call (include/rem2d.h) ----
+// Graph replay: the launches of one call (n_steps x groups x 3-4 kernels, fork / join edges between the streams) are
+// captured once and replayed with one hipGraphLaunch per call; the kernel arguments are by-value structs that only
+// change when a world's tile table / outputs / terrain change (epoch).
+struct GraphEntry {
+    uint64_t key;
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+};
+static std::vector<GraphEntry> g_graphs;
+static hipStream_t g_captureStream = nullptr;
+static uint64_t mix64(uint64_t h, uint64_t v) {
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    return h;
+}
+
+static int groups_enqueue(const rem2d_step_group *groups, int n_groups, int n_steps, float dt, int vel_iters, int pos_iters,
+                          hipStream_t origin, bool tiles) {
+    // fork: every group stream waits for what the origin stream has queued so far
+    rem2d_world *w00 = groups[0].worlds[0];
+    bool forked = false;
+    for (int g = 0; g < n_groups; ++g) {
+        hipStream_t sg = groups[g].stream ? (hipStream_t)groups[g].stream : origin;
+        if (sg == origin) continue;
+        if (!forked) {
+            HIP_TRY(hipEventRecord(w00->evFork, origin));
+            forked = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(sg, w00->evFork, 0));
+    }
+    if (tiles) {
+        // round-robin: step l of every group is queued before step l + 1 of any, so that no group's stream runs dry while
+        // the host is still busy queueing another group's whole train (and the groups start together)
+        std::vector<TilePlan> plans((size_t)n_groups);
+        for (int g = 0; g < n_groups; ++g) tiles_plan(plans[g], groups[g].worlds, groups[g].n_worlds, dt, vel_iters, pos_iters);
+        for (int l = 0; l < n_steps; ++l)
+            for (int g = 0; g < n_groups; ++g)
+                tiles_launch_step(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin);
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (int g = 0; g < n_groups; ++g) {
+            int rc = step_fused(groups[g].worlds, groups[g].n_worlds, n_steps, dt, vel_iters, pos_iters,
+                                groups[g].stream ? (hipStream_t)groups[g].stream : origin);
+            if (rc != REM2D_OK) return rc;
+        }
+    }
+    // join: the origin stream waits for every group
+    for (int g = 0; g < n_groups; ++g) {
+        hipStream_t sg = groups[g].stream ? (hipStream_t)groups[g].stream : origin;
+        if (sg == origin) continue;
+        rem2d_world *wg = groups[g].worlds[0];
+        HIP_TRY(hipEventRecord(wg->evJoin, sg));
+        HIP_TRY(hipStreamWaitEvent(origin, wg->evJoin, 0));
+    }
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, float dt,
+                                    int32_t vel_iters, int32_t pos_iters, void *stream, uint32_t flags) {
+    if (!groups || n_groups <= 0) return fail(REM2D_E_INVALID, "no step groups");
+    if (n_groups > REM2D_MAX_STEP_GROUPS) return fail(REM2D_E_INVALID, "too many step groups");
+    rem2d_world *w00 = nullptr;
+    bool timing = false;
+    for (int g = 0; g < n_groups; ++g) {
+        if (!groups[g].worlds || groups[g].n_worlds <= 0) return fail(REM2D_E_INVALID, "a step group has no worlds");
+        if (groups[g].n_worlds > REM2D_MAX_WORLDS_PER_STEP) return fail(REM2D_E_INVALID, "too many worlds in one step group");
+        for (int i = 0; i < groups[g].n_worlds; ++i) {
+            rem2d_world *w = groups[g].worlds[i];
+            if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+            if (!w00) w00 = w;
+            if (!w->haveTerrain) return fail(REM2D_E_STATE, "rem2d_world_set_terrain must be called before step");
+            if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
+            if (w->cfg.device != w00->cfg.device) return fail(REM2D_E_INVALID, "step groups of one call must share the device");
+            if ((w->cfg.flags & REM2D_FLAG_CONTINUOUS) != (groups[g].worlds[0]->cfg.flags & REM2D_FLAG_CONTINUOUS))
+                return fail(REM2D_E_INVALID, "worlds of one launch must agree on REM2D_FLAG_CONTINUOUS");
+            timing = timing || w->timing;
+        }
+    }
+    if (n_steps <= 0) return REM2D_OK;
+    HIP_TRY(hipSetDevice(w00->cfg.device));
+    for (int g = 0; g < n_groups; ++g) {
+        rem2d_world *wg = groups[g].worlds[0];
+        if (!wg->evFork) HIP_TRY(hipEventCreateWithFlags(&wg->evFork, hipEventDisableTiming));
+        if (!wg->evJoin) HIP_TRY(hipEventCreateWithFlags(&wg->evJoin, hipEventDisableTiming));
+    }
+    const bool tiles = pipeline_mode() == 3;
+    hipStream_t origin = (hipStream_t)stream;
+    if (!(flags & REM2D_STEP_GRAPH) || timing || !tiles)
+        return groups_enqueue(groups, n_groups, n_steps, dt, vel_iters, pos_iters, origin, tiles);
+
+    // ---- graph replay ----
+    uint64_t key = mix64(0x5bd1e995u, (uint64_t)n_steps);
+    key = mix64(key, (uint64_t)__float_as_uint_host(dt));
+    key = mix64(key, ((uint64_t)(uint32_t)vel_iters << 32) | (uint32_t)pos_iters);
+    for (int g = 0; g < n_groups; ++g) {
+        key = mix64(key, (uint64_t)(uintptr_t)groups[g].stream);
+        for (int i = 0; i < groups[g].n_worlds; ++i) {
+            key = mix64(key, (uint64_t)(uintptr_t)groups[g].worlds[i]);
+            key = mix64(key, groups[g].worlds[i]->epoch);
+        }
+        key = mix64(key, 0xfeedull + (uint64_t)groups[g].n_worlds);
+    }
+    GraphEntry *hit = nullptr;
+    for (auto &e : g_graphs)
+        if (e.key == key) hit = &e;
+    if (!hit) {
+        if (!g_captureStream) HIP_TRY(hipStreamCreateWithFlags(&g_captureStream, hipStreamNonBlocking));
+        // the capture starts on a stream of the library's own (the caller's may be the NULL stream, which cannot capture);
+        // group streams are pulled into the capture by the fork events
+        std::vector<rem2d_step_group> cg(groups, groups + n_groups);
+        HIP_TRY(hipStreamBeginCapture(g_captureStream, hipStreamCaptureModeRelaxed));
+        int rc = groups_enqueue(cg.data(), n_groups, n_steps, dt, vel_iters, pos_iters, g_captureStream, true);
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(g_captureStream, &graph);
+        if (rc != REM2D_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return fail(REM2D_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return fail(REM2D_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        if (g_graphs.size() >= 16) { // worlds come and go (compact(), reset): drop the oldest replay
+            (void)hipGraphExecDestroy(g_graphs.front().exec);
+            (void)hipGraphDestroy(g_graphs.front().graph);
+            g_graphs.erase(g_graphs.begin());
+        }
+        g_graphs.push_back({key, exec, graph});
+        hit = &g_graphs.back();
+    }
+    HIP_TRY(hipGraphLaunch(hit->exec, origin));
+    return REM2D_OK;
+}
+extern "C" int rem2d_groups_step(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, void *stream, uint32_t flags) {
+    return rem2d_groups_step_ex(groups, n_groups, n_steps, (float)(1.0 / 50), 6 * 30, 2 * 30, stream, flags);
 }
 
 extern "C" int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_dev, int32_t n_trees, int32_t max_nodes,

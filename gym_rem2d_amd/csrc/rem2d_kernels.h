@@ -127,7 +127,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
         Rot q = rot_set(ang); // body transform m_xf (q from sweep.a, p = c since localCenter = 0)
         // ---- b2ContactManager::Collide: destroy separated pairs, update manifolds ----
         int nTouch = 0;
-        unsigned slotPack = 0u;
+        slotpack_t slotPack = 0;
         if (active && awake) {
             int s = 0;
             while (s < cCount) {
@@ -144,7 +144,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
                 if (m.count > 0) {
                     if (nTouch < KT) {
                         manifold_store(S, gl, nTouch, m);
-                        slotPack |= (unsigned)s << (5 * nTouch);
+                        slotPack |= SP_PUT(s, nTouch);
                         ++nTouch;
                     } else {
                         err |= REM2D_ERR_SOLVER_OVERFLOW;
@@ -176,7 +176,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
                 if (t < nTouch) {
                     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
                     int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
+                    unsigned o = SP_GET(slotPack, t) * Lp + gl;
                     contact_setup(cc[t], tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
                                   mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
                                   dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o), dtRatio * CF(C_N1, o), dtRatio * CF(C_T1, o));
@@ -187,7 +187,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
                 for (int t = KR; t < nTouch; ++t) {
                     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
                     int tc = __float_as_int(SW(sb, 0));
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
+                    unsigned o = SP_GET(slotPack, t) * Lp + gl;
                     ContactC c;
                     contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)),
                                   mk(SW(sb, 5), SW(sb, 6)), mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB,
@@ -365,7 +365,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
 #pragma unroll
             for (int t = 0; t < KR; ++t) {
                 if (t < nTouch) {
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
+                    unsigned o = SP_GET(slotPack, t) * Lp + gl;
                     CF(C_N0, o) = cc[t].n0;
                     CF(C_T0, o) = cc[t].t0;
                     if (cc[t].count > 1) {
@@ -377,7 +377,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
             if (anyOverflow) {
                 for (int t = KR; t < nTouch; ++t) {
                     const unsigned cb = (unsigned)(KT * SCR_WORDS + (t - KR) * CC_WORDS) * S.Lp + gl;
-                    unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
+                    unsigned o = SP_GET(slotPack, t) * Lp + gl;
                     CF(C_N0, o) = SW(cb, 10);
                     CF(C_T0, o) = SW(cb, 12);
                     if (__float_as_int(SW(cb, 20)) > 1) {

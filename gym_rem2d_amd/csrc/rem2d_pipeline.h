@@ -89,7 +89,7 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     Rot q = rot_set(ang);
     // ---- b2ContactManager::Collide: destroy separated pairs, update manifolds ----
     int nTouch = 0;
-    unsigned slotPack = 0u;
+    slotpack_t slotPack = 0;
     if (active && awake) {
         int s = 0;
         while (s < cCount) {
@@ -105,7 +105,7 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
             if (m.count > 0) {
                 if (nTouch < KT) {
                     manifold_store(S, gl, nTouch, m);
-                    slotPack |= (unsigned)s << (5 * nTouch);
+                    slotPack |= SP_PUT(s, nTouch);
                     ++nTouch;
                 } else {
                     err |= REM2D_ERR_SOLVER_OVERFLOW;
@@ -130,7 +130,7 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
         for (int t = 0; t < nTouch; ++t) {
             const unsigned sb = (unsigned)(t * SCR_WORDS) * Lp + gl;
             int tc = __float_as_int(SW(sb, 0));
-            unsigned o = ((slotPack >> (5 * t)) & 0x1f) * Lp + gl;
+            unsigned o = SP_GET(slotPack, t) * Lp + gl;
             ContactC c;
             contact_setup(c, tc & 0xff, tc >> 8, mk(SW(sb, 1), SW(sb, 2)), mk(SW(sb, 3), SW(sb, 4)), mk(SW(sb, 5), SW(sb, 6)),
                           mk(SW(sb, 7), SW(sb, 8)), mk(px, py), q, mB, iB, radiusB, dtRatio * CF(C_N0, o), dtRatio * CF(C_T0, o),
@@ -175,7 +175,7 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     {
         const unsigned mb = (unsigned)SCR_MISC_BASE * Lp + gl;
         SW(mb, 0) = __int_as_float(nTouch | (envAwake ? 0x100 : 0));
-        SW(mb, 1) = __int_as_float((int)slotPack);
+        sp_store(S, mb, slotPack);
     }
     int envErr = group_or<K>(err);
     if (sub == 0) {

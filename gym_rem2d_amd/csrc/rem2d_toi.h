@@ -373,8 +373,22 @@ DEV void manifold_store(const State &S, unsigned gl, int t, const Manifold &m) {
 #define SCR_TOI_BASE (KT * SCR_WORDS + KT * CC_WORDS)
 #define SCR_SWEEP_BASE (SCR_TOI_BASE + KC) // c0.x, c0.y, a0 handed from the step kernel to the TOI kernel
 #define SCR_MISC_BASE (SCR_SWEEP_BASE + 3)  // split pipeline: [0] nTouch | solve << 8, [1] pair-slot map of the touching contacts
-#define SCR_JREC_BASE (SCR_MISC_BASE + 2)   // split pipeline: joint lever arms rA.x rA.y rB.x rB.y
+#define SCR_JREC_BASE (SCR_MISC_BASE + 1 + SP_WORDS)   // split pipeline: joint lever arms rA.x rA.y rB.x rB.y
 #define SCR_TOTAL_WORDS (SCR_JREC_BASE + 4)
+// the pair-slot map in the misc record (words 1 .. SP_WORDS)
+DEV void sp_store(const State &S, unsigned mb, slotpack_t p) {
+    SW(mb, 1) = __int_as_float((int)(unsigned)p);
+#if SP_WORDS == 2
+    SW(mb, 2) = __int_as_float((int)(unsigned)(p >> 32));
+#endif
+}
+DEV slotpack_t sp_load(const State &S, unsigned mb) {
+    slotpack_t p = (unsigned)__float_as_int(SW(mb, 1));
+#if SP_WORDS == 2
+    p |= (slotpack_t)(unsigned)__float_as_int(SW(mb, 2)) << 32;
+#endif
+    return p;
+}
 
 // Exact early-outs of the TOI query for (static proxy pA, this body's proxy pB swept by sw): true means
 // b2TimeOfImpact would answer "separated" (alpha = 1) without it having to run.
@@ -592,9 +606,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
         B.events += 1;
         // ---- TOI island: this body, the TOI contact, then its other touching contacts (list order) ----
         int nIsl = 0;
-        unsigned islPack = 0u;
         island_store(ts, lane, 0, m);
-        islPack |= (unsigned)minSlot;
         nIsl = 1;
         CI(C_INFO, om) = CI(C_INFO, om) | CI_ISLAND;
         for (int s = 0; s < B.cCount; ++s) {
@@ -605,7 +617,6 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             if (mo.count == 0) continue;
             if (nIsl >= KT) { B.err |= REM2D_ERR_SOLVER_OVERFLOW; continue; }
             island_store(ts, lane, nIsl, mo);
-            islPack |= (unsigned)s << (5 * nIsl);
             ++nIsl;
         }
         TOI_STAMP(1); // contact updates (TOI contact + the body's other pairs)

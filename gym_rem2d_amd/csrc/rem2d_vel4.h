@@ -180,11 +180,12 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
 struct ContactT {
     ContactC c;
     float mB;
-    int key; // body | sub-slot << 8 | manifold index << 11 | first tick << 16 | (first tick mod P) << 24 | valid << 31
+    int key; // body | sub-slot << 8 | manifold index << 12 | first tick << 16 | (first tick mod P) << 24 | valid << 31
 };
 #define V4_CBODY(k) ((k) & 0xff)
-#define V4_CSUB(k) (((k) >> 8) & 0x7)
-#define V4_CT(k) (((k) >> 11) & 0x7)
+#define V4_CSUB(k) (((k) >> 8) & 0xf)
+#define V4_CT(k) (((k) >> 12) & 0xf)
+static_assert(KT <= 16, "manifold index: 4 bits");
 #define V4_COFF(k) (((k) >> 16) & 0xff)
 #define V4_CPHASE(k) (((k) >> 24) & 0x7)
 
@@ -382,7 +383,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
 #pragma unroll
         for (int t = 0; t < KT; ++t) { // manifold t of every body: ranks in (pass, t, lane) order, sub-slot t
             const unsigned long long cm = __ballot(nT > t);
-            if (nT > t) sh.cmap[NC + __popcll(cm & below)] = (unsigned)(bl | (t << 8) | (t << 11) | (off << 16) | (cph << 24));
+            if (nT > t) sh.cmap[NC + __popcll(cm & below)] = (unsigned)(bl | (t << 8) | (t << 12) | (off << 16) | (cph << 24));
             NC += __popcll(cm);
         }
         maxT = max(maxT, nT);
@@ -519,8 +520,8 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         if (V4_VALID(C[cs].key)) {
             const int b = V4_CBODY(C[cs].key), t = V4_CT(C[cs].key);
             const unsigned gl = tb0 + (unsigned)b;
-            const unsigned sp = (unsigned)__float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 1));
-            const unsigned o = ((sp >> (5 * t)) & 0x1f) * Lp + gl;
+            const slotpack_t sp = sp_load(S, (unsigned)SCR_MISC_BASE * Lp + gl);
+            const unsigned o = SP_GET(sp, t) * Lp + gl;
             CF(C_N0, o) = C[cs].c.n0;
             CF(C_T0, o) = C[cs].c.t0;
             if (C[cs].c.count > 1) {
@@ -535,8 +536,8 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             const int b = V4_CBODY(e), t = V4_CT(e);
             const unsigned gl = tb0 + (unsigned)b;
             const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
-            const unsigned sp = (unsigned)__float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 1));
-            const unsigned o = ((sp >> (5 * t)) & 0x1f) * Lp + gl;
+            const slotpack_t sp = sp_load(S, (unsigned)SCR_MISC_BASE * Lp + gl);
+            const unsigned o = SP_GET(sp, t) * Lp + gl;
             CF(C_N0, o) = SW(cb, 10);
             CF(C_T0, o) = SW(cb, 12);
             if (__float_as_int(SW(cb, 20)) > 1) {

@@ -56,13 +56,30 @@ def _uniform(m):
     return all(bool((m.arrays[k].reshape(n, K) == m.arrays[k][:K]).all()) for k in ("shape", "parent", "jround"))
 
 
+_GROUP_STREAMS = {}   # device -> the step-group streams of this process
+
+
+def group_streams(device, n):
+    """The n - 1 HIP streams step groups 1 .. n-1 run on (group 0 runs on the caller's stream), shared by every
+    BatchedModular2D of the process: HIP maps streams onto a few hardware queues and streams that share a queue serialise,
+    so a second env must not bring streams of its own (65 536 CPPN creatures: 24.8 M env-steps/s on the 6th-8th stream
+    of a process, 45 M on the first three)."""
+    pool = _GROUP_STREAMS.setdefault(str(device), [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=device))
+    return [None] + pool[:max(0, n - 1)]
+
+
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
     BIG_POPULATION = 160000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
 
-    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None):
+    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
+        # wide: the worlds live in librem2d_wide.so (32 pair slots / 12 solver slots per body; evaluate.run_episode re-runs
+        # there the creatures that overflowed the default build's slots)
         from . import _lib
+        self.wide = bool(wide)
         self.hardcore, self.flat = hardcore, flat
         self.flags = _lib.FLAG_CONTINUOUS if flags is None else flags
         self.device = device
@@ -82,6 +99,8 @@ class BatchedModular2D:
         # tiles (2.4x fewer wave-instructions) do: 62.1 vs 58.0 M env-steps/s at 196 608 creatures.
         self.tile_shape = None
         self.groups, self.group_streams = [], []
+        self._group_args = None
+        self.use_graph = os.environ.get("REM2D_GRAPH", "0") == "1"   # replay every step call as a hipGraph
 
     def seed(self, seed=None):
         self._seed = seed
@@ -130,9 +149,11 @@ class BatchedModular2D:
             w.close()
         self.worlds = []
         self._world_morph = []   # host-side layout of every world's creatures (compact() re-plans tiles from it)
+        self._uploaded = [(m, np.asarray(idx, dtype=np.int64)) for m, idx in batches]   # (evaluate.run_episode's fallback)
         self._compacted = False
         self._inactive = set()   # worlds compact() found without a single open fitness
         self._tile_shape_used = None
+        self._group_args = None
         self.n_envs = n_envs
         self.streams = []
         # Step groups: a step is a chain of four launches, each as long as its slowest wavefront; independent parts of the
@@ -185,19 +206,17 @@ class BatchedModular2D:
                     pieces.append((g, mem[lo:lo + per]))
             for g, mem in pieces:
                 part = morph if len(mem) == morph.n_envs else morph.take(mem)
-                w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device)
+                w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device, wide=self.wide)
                 w.set_terrain(self._terrain())
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
                 self.worlds.append((w, torch.as_tensor(idx[mem], dtype=torch.long, device=w.device)))
                 self._world_morph.append(part)
-                # fallback path (REM2D_MERGED_LAUNCH=0): one HIP stream per world
-                self.streams.append(torch.cuda.Stream(device=w.device))
         self.groups = [g for g in self.groups if g]
         dev = self.worlds[0][0].device
         # the first group runs on the caller's stream: four streams in all is what the device overlaps well (a fifth costs
         # 5-25 %: 4 groups on 4 new streams 36.7 M, on the caller's + 3 new ones 40.2 M env-steps/s for config 3)
-        self.group_streams = [None] + [torch.cuda.Stream(device=dev) for _ in self.groups[1:]]
+        self.group_streams = group_streams(dev, len(self.groups))
         self._reward = torch.zeros(n_envs, dtype=torch.float32, device=dev)
         self._done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
         self._fitness = torch.zeros(n_envs, dtype=torch.float64, device=dev)
@@ -231,28 +250,28 @@ class BatchedModular2D:
     def step(self, n_steps=1):
         if len(self.worlds) == 1:
             self.worlds[0][0].step(n_steps)
-        elif self.merged_launch and all(len(g) <= _lib.MAX_WORLDS_PER_STEP for g in self.groups):
-            # all lane buckets of a group in one grid per kernel (rem2d_worlds_step): the dispatcher packs the
-            # small buckets next to the big one; on separate streams they mostly ran one after the other
-            cur = torch.cuda.current_stream(self.worlds[0][0].device)
-            for st in self.group_streams:
-                if st is not None:
-                    st.wait_stream(cur)
-            order = sorted(range(len(self.groups)), key=lambda k: self.group_streams[k] is None)  # the caller's stream last
-            for k in order:
-                g, st = self.groups[k], self.group_streams[k]
-                handles = (C.c_void_p * len(g))(*[self.worlds[i][0].h for i in g])
-                if st is None:
-                    _lib.check(_lib.lib().rem2d_worlds_step(handles, len(g), int(n_steps), self.worlds[g[0]][0]._stream()))
-                else:
-                    with torch.cuda.stream(st):
-                        _lib.check(_lib.lib().rem2d_worlds_step(handles, len(g), int(n_steps),
-                                                                self.worlds[g[0]][0]._stream()))
-            for st in self.group_streams:
-                if st is not None:
-                    cur.wait_stream(st)
+        elif (self.merged_launch and len(self.groups) <= _lib.MAX_STEP_GROUPS
+              and all(len(g) <= _lib.MAX_WORLDS_PER_STEP for g in self.groups)):
+            # all lane buckets of a group in one grid per kernel, all groups in ONE ABI call (rem2d_groups_step): fork from
+            # the caller's stream, the steps of the groups queued round-robin, join -- or the whole call replayed as a
+            # hipGraph (REM2D_GRAPH=1)
+            if self._group_args is None:
+                arrs = [(C.c_void_p * len(g))(*[self.worlds[i][0].h for i in g]) for g in self.groups]
+                sg = (_lib.StepGroup * len(self.groups))()
+                for k, (g, st) in enumerate(zip(self.groups, self.group_streams)):
+                    sg[k].worlds = C.cast(arrs[k], C.POINTER(C.c_void_p))
+                    sg[k].n_worlds = len(g)
+                    sg[k].stream = None if st is None else st.cuda_stream
+                self._group_args = (sg, arrs)
+            _lib.check(_lib.lib(self.wide).rem2d_groups_step(self._group_args[0], len(self.groups), int(n_steps),
+                                                             self.worlds[self.groups[0][0]][0]._stream(),
+                                                             _lib.STEP_GRAPH if self.use_graph else 0), self.wide)
         else:
+            # fallback path (REM2D_MERGED_LAUNCH=0, or more lane buckets than one launch takes): one HIP stream per world,
+            # created on first use
             cur = torch.cuda.current_stream(self.worlds[0][0].device)
+            while len(self.streams) < len(self.worlds):
+                self.streams.append(torch.cuda.Stream(device=self.worlds[0][0].device))
             for wi, ((w, _), st) in enumerate(zip(self.worlds, self.streams)):
                 if wi in self._inactive:
                     continue
@@ -268,11 +287,11 @@ class BatchedModular2D:
 
     def _gather(self, name, out):
         if len(self.worlds) == 1 and not self._compacted:
-            return self.worlds[0][0].view(name)
+            return self.worlds[0][0].view(name).clone()   # a snapshot, like the multi-world path
         for wi, (w, idx) in enumerate(self.worlds):   # (creatures compact() has dropped keep the values it stored in `out`)
             if wi not in self._inactive:
                 out.index_copy_(0, idx, w.view(name).to(out.dtype))
-        return out
+        return out.clone()   # (`out` is the persistent population-order buffer compact() writes to: callers get a snapshot)
 
     # ---- evaluate(): drop the creatures whose fitness is final ----
     def compact(self, min_envs=2048, max_alive=0.5):
@@ -310,7 +329,7 @@ class BatchedModular2D:
                 self._inactive.update(wis)
                 continue
             part = Morphology.concat([self._world_morph[wi].take(k.cpu().numpy()) for wi, k in zip(wis, keeps) if k.numel()])
-            nw = BatchedWorld(n_keep, lanes, self.flags, self.device)
+            nw = BatchedWorld(n_keep, lanes, self.flags, self.device, wide=self.wide)
             nw.set_terrain(self._terrain())
             for name in _lib.FIELDS:
                 dst = nw.view(name)
@@ -321,10 +340,10 @@ class BatchedModular2D:
             new_idx = torch.cat([self.worlds[wi][1][k] for wi, k in zip(wis, keeps) if k.numel()])
             nw.set_outputs(self._reward, self._done, new_idx.to(torch.int32))
             torch.cuda.synchronize(nw.device)   # the old arenas must outlive the copies
-            for wi in wis[1:]:   # (their arenas are released; the entries stay so that world indices do not move)
+            for wi in wis[1:]:   # (the entries stay so that world indices do not move; the arenas go)
                 self._inactive.add(wi)
-                self.worlds[wi][0].close()
-            self.worlds[wis[0]][0].close()
+                self.worlds[wi][0].release()
+            self.worlds[wis[0]][0].release()
             self.worlds[wis[0]] = (nw, new_idx)
             self._world_morph[wis[0]] = part
         if changed:
@@ -335,7 +354,8 @@ class BatchedModular2D:
             if sum(self.worlds[i][0].n_envs for i in active) < 16384 and len(active) <= _lib.MAX_WORLDS_PER_STEP:
                 groups = [active] if active else []   # too few creatures for step groups to pay: one launch sequence
             self.groups = groups
-            self.group_streams = [None] + [torch.cuda.Stream(device=self._reward.device) for _ in groups[1:]]
+            self.group_streams = self.group_streams[:max(1, len(groups))]   # (the first is the caller's stream: None)
+            self._group_args = None
         return alive_total
 
     @property

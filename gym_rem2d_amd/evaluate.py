@@ -82,12 +82,7 @@ def check_errors(env, on_error="raise"):
     return bad
 
 
-def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="raise", compact=True):
-    """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
-    Returns fitness[N] (float64 tensor on the env's device).  Engine overflows (see SolverOverflow) are not silent:
-    by default they raise once the episode is over.  compact: in worlds created with REM2D_FLAG_SKIP_FROZEN (the
-    bodies of finished creatures are nobody's business any more) the survivors are moved into smaller worlds between
-    chunks once most of a world has finished (BatchedModular2D.compact) -- same fitness, a shorter episode."""
+def _episode(env, max_steps, chunk, compact):
     done_steps = 0
     compact = compact and bool(env.flags & _lib.FLAG_SKIP_FROZEN)
     while done_steps < max_steps:
@@ -99,15 +94,77 @@ def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="raise", compact
                 break
         elif bool((env.frozen != 0).all()):
             break
+
+
+def reevaluate_wide(env, bad, fit, max_steps=EPISODE_CAP, chunk=100):
+    """The overflow fallback.  Box2D has no cap on the contacts of a body (Modular2DEnv.py:634 world.Step solves whatever
+    touches); the default build keeps 24 pair slots / 6 solver slots per body in HBM / registers and flags the creature
+    that needs more.  Creatures are independent and an episode is a function of the morphology alone, so the flagged ones
+    (``bad``: bool [N] in population order) are simply evaluated again, from reset, in worlds of the wide build
+    (librem2d_wide.so: 32 / 12 slots) -- same kernels, same arithmetic, same bits for everything that fits both.  Writes
+    their fitness into ``fit`` and returns the mask of creatures that overflowed even there."""
+    from .env import BatchedModular2D
+    idx_bad = torch.nonzero(bad).flatten().cpu().numpy()
+    still = torch.zeros_like(bad)
+    if idx_bad.size == 0:
+        return still
+    wide = BatchedModular2D(hardcore=env.hardcore, flat=env.flat, seed=env._seed, device=env.device, flags=env.flags,
+                            wide=True)
+    wide.terrain = env._terrain()
+    batches = []
+    for morph, idx in env._uploaded:
+        sel = np.nonzero(np.isin(idx, idx_bad))[0]
+        if sel.size:
+            batches.append((morph.take(sel), np.searchsorted(idx_bad, idx[sel]).tolist()))
+    wide._upload(batches, int(idx_bad.size))
+    _episode(wide, max_steps, chunk, compact=False)
+    where = torch.as_tensor(idx_bad, dtype=torch.long, device=fit.device)
+    fit.index_copy_(0, where, wide.fitness.to(fit.device))
+    still.index_copy_(0, where, (wide.errors() != 0).to(still.device))
+    wide.close()
+    return still
+
+
+def run_episode_masked(env, max_steps=EPISODE_CAP, chunk=100, compact=True, fallback=True):
+    """run_episode without the verdict: (fitness [N] float64, unresolved [N] bool).  ``unresolved`` marks the creatures
+    whose fitness is NOT what the reference's Box2D computes: they overflowed the default build's contact capacity and
+    (with ``fallback``) the wide build's as well.  Never raises on overflow -- what a sharded job calls before its
+    collective (a rank that raised here would leave the others waiting in the all-gather)."""
+    _episode(env, max_steps, chunk, compact)
+    fit = env.fitness.clone()
+    bad = check_errors(env, "ignore")
+    env.last_overflow = torch.nonzero(bad).flatten().cpu().tolist()   # population indices that needed the fallback
+    if fallback and bool(bad.any()):
+        bad = reevaluate_wide(env, bad, fit, max_steps, chunk)
+    return fit, bad
+
+
+def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="fallback", compact=True):
+    """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
+    Returns fitness[N] (float64 tensor on the env's device).  Engine overflows (see SolverOverflow) are not silent and,
+    by default, not fatal: on_error="fallback" re-evaluates the flagged creatures in the wide build (reevaluate_wide) so
+    that every individual gets the fitness Box2D would give, and raises only for creatures that overflow even that;
+    "raise" / "warn" / "ignore" judge the default build's flags without a second attempt.  compact: in worlds created
+    with REM2D_FLAG_SKIP_FROZEN (the bodies of finished creatures are nobody's business any more) the survivors are
+    moved into smaller worlds between chunks once most of a world has finished (BatchedModular2D.compact) -- same
+    fitness, a shorter episode."""
+    if on_error == "fallback":
+        fit, bad = run_episode_masked(env, max_steps, chunk, compact, fallback=True)
+        if bool(bad.any()):
+            idx = torch.nonzero(bad).flatten().cpu().tolist()
+            raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+        return fit
+    _episode(env, max_steps, chunk, compact)
     check_errors(env, on_error)
     return env.fitness.clone()
 
 
-def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, workers=None, on_error="raise",
+def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISODE_CAP, workers=None, on_error="fallback",
                         **env_kw):
     """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats.
     The genotype -> phenotype step runs on ``workers`` host processes (encode.encode_population).
-    on_error: what to do when a creature overflowed the engine's contact capacity ("raise" | "warn" | "ignore")."""
+    on_error: what to do when a creature overflowed the engine's contact capacity ("fallback": re-evaluate it in the
+    wide build, the default | "raise" | "warn" | "ignore")."""
     from .encode import encode_population
     from .env import BatchedModular2D
     own = env is None
@@ -126,8 +183,12 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
             len({ind.genome.maxModules for ind in individuals}) == 1:
         # network genomes (feed-forward CPPN): the NN queries that grow the tree run natively as well
         from .encode import encode_network_native
-        depth = tree_depth if tree_depth is not None else individuals[0].tree_depth
-        batches = encode_network_native(individuals, depth, n_threads=workers or 0)
+        depths = {tree_depth} if tree_depth is not None else {ind.tree_depth for ind in individuals}
+        if len(depths) == 1:
+            batches = encode_network_native(individuals, depths.pop(), n_threads=workers or 0)
+        else:   # individuals with their own tree depths: the node-by-node compiler expresses each with its own
+            from .encode import encode_trees_native
+            batches = encode_trees_native(individuals, tree_depth, n_threads=workers or 0)
     else:
         # every other encoding: python hands out the phenotype trees, the native compiler builds the creatures
         from .encode import encode_trees_native
@@ -151,27 +212,48 @@ def shard_range(n, rank, world_size):
     return lo, min(n, lo + per)
 
 
-def all_gather_fitness(local, n_total, group=None):
+def all_gather_fitness(local, n_total, group=None, flags=None):
     """One all_gather of float64 fitness scalars: [per] -> [n_total] on every rank.  `local` is padded to ceil(n/W) so
     that the collective is a single equal-sized all_gather_into_tensor.  float64 like the reference's python floats
     (REM2D_main.py:372-375 compares ``reward + (10000 - i) / 10000`` in doubles): a sharded and a single-GPU run return
-    the same values, so tournament winners cannot depend on the world size.  8 MiB at 1 M individuals."""
+    the same values, so tournament winners cannot depend on the world size.  8 MiB at 1 M individuals.
+    flags: optional bool / int [per] mask of the rank's creatures without a valid fitness (run_episode_masked); it rides
+    in the same collective as a second column and the call returns (fitness [n_total], flags [n_total] bool) -- every
+    rank learns about every rank's failures AFTER the collective and can raise in step."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = math.ceil(n_total / world)
-    buf = torch.zeros(per, dtype=torch.float64, device=local.device)
-    buf[:local.numel()] = local.to(torch.float64)
-    out = torch.empty(per * world, dtype=torch.float64, device=local.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
-    return out[:n_total]
+    cols = 1 if flags is None else 2
+    buf = torch.zeros(cols, per, dtype=torch.float64, device=local.device)
+    buf[0, :local.numel()] = local.to(torch.float64)
+    if flags is not None:
+        buf[1, :local.numel()] = torch.as_tensor(flags, device=local.device).to(torch.float64)
+    out = torch.empty(world * cols * per, dtype=torch.float64, device=local.device)
+    dist.all_gather_into_tensor(out, buf.reshape(-1), group=group)
+    out = out.view(world, cols, per)
+    fit = out[:, 0].reshape(-1)[:n_total]
+    if flags is None:
+        return fit
+    return fit, out[:, 1].reshape(-1)[:n_total] != 0
 
 
 def evaluate_population_sharded(n_total, local_eval, group=None, device=None):
     """Shard [0, n_total) over the job's ranks, evaluate the local block with
-    ``local_eval(lo, hi) -> tensor[hi-lo]`` and all-gather.  Returns fitness[n_total] (float64)."""
+    ``local_eval(lo, hi) -> tensor[hi-lo]`` (or ``-> (tensor, unresolved mask)``, run_episode_masked) and all-gather.
+    Returns fitness[n_total] (float64).  A creature without a valid fitness on ANY rank raises SolverOverflow on EVERY
+    rank, after the collective."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_total, rank, world)
     local = local_eval(lo, hi)
+    mask = None
+    if isinstance(local, tuple):
+        local, mask = local
     local = torch.as_tensor(local, dtype=torch.float64, device=device if device is not None else None)
-    return all_gather_fitness(local, n_total, group)
+    if mask is None:
+        mask = torch.zeros(local.numel(), dtype=torch.bool, device=local.device)
+    fit, bad = all_gather_fitness(local, n_total, group, flags=torch.as_tensor(mask, device=local.device))
+    if bool(bad.any()):
+        idx = torch.nonzero(bad).flatten().cpu().tolist()
+        raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+    return fit

@@ -215,16 +215,31 @@ def sharded_evaluator(local_eval, group=None, device=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         lo, hi = shard_range(len(pop), rank, world)
         local = local_eval(pop.select(np.arange(lo, hi))) if hi > lo else np.zeros(0, dtype=np.float64)
+        mask = None
+        if isinstance(local, tuple):     # (fitness, unresolved mask): gpu_evaluator(masked=True)
+            local, mask = local
         local = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
-        return all_gather_fitness(local, len(pop), group).cpu().numpy().astype(np.float64)
+        mask = torch.zeros(local.numel(), dtype=torch.bool) if mask is None else torch.as_tensor(np.asarray(mask))
+        # the mask rides in the fitness all-gather: a rank with a creature that has no valid fitness does not raise
+        # before the collective (the others would wait in it for ever) -- every rank raises after it
+        fit, bad = all_gather_fitness(local, len(pop), group, flags=mask.to(local.device))
+        if bool(bad.any()):
+            from .evaluate import SolverOverflow
+            from . import _lib
+            idx = torch.nonzero(bad).flatten().cpu().tolist()
+            raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+        return fit.cpu().numpy().astype(np.float64)
     return evaluate
 
 
-def gpu_evaluator(env=None, max_steps=None, n_threads=0):
+def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False):
     """local_eval for sharded_evaluator / evaluate for run_generations on one GPU: native expression, upload,
-    whole episodes (evaluate()'s rule), fitness as float64 numpy."""
+    whole episodes (evaluate()'s rule), fitness as float64 numpy.  Creatures that overflow the default build's contact
+    slots are re-evaluated in the wide build (evaluate.reevaluate_wide); one that overflows even that raises
+    SolverOverflow -- or, with masked=True (what a sharded job wants), comes back in a second array
+    ``(fitness, unresolved)`` so that nothing raises before the job's collective."""
     from .env import BatchedModular2D
-    from .evaluate import EPISODE_CAP, run_episode
+    from .evaluate import EPISODE_CAP, run_episode, run_episode_masked
     holder = {"env": env}
 
     def evaluate(pop):
@@ -234,5 +249,9 @@ def gpu_evaluator(env=None, max_steps=None, n_threads=0):
         e = holder["env"]
         e.trees = e.robots = None
         e._upload(pop.compile(n_threads), len(pop))
-        return run_episode(e, max_steps if max_steps is not None else EPISODE_CAP).cpu().numpy()
+        cap = max_steps if max_steps is not None else EPISODE_CAP
+        if masked:
+            fit, bad = run_episode_masked(e, cap)
+            return fit.cpu().numpy(), bad.cpu().numpy()
+        return run_episode(e, cap).cpu().numpy()
     return evaluate

@@ -18,12 +18,15 @@ _DTYPES = {0: torch.float32, 1: torch.int32, 2: torch.float64}
 
 
 class BatchedWorld:
-    def __init__(self, n_envs, lanes, flags=0, device=None):
+    def __init__(self, n_envs, lanes, flags=0, device=None, wide=False):
+        """wide: use librem2d_wide.so (32 pair slots / 12 solver slots per body instead of 24 / 6)."""
         if not torch.cuda.is_available():
             raise _lib.Rem2dError("gym_rem2d_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.n_envs, self.lanes, self.flags = int(n_envs), int(lanes), int(flags)
-        L = _lib.lib()
+        self.wide = bool(wide)
+        L = self.L = _lib.lib(self.wide)
+        self.contact_slots = _lib.capacity(self.wide)[0]
         self.cfg = _lib.WorldCfg(self.n_envs, self.lanes, self.flags, self.device.index or 0)
         nbytes = L.rem2d_state_bytes(C.byref(self.cfg))
         if nbytes == 0:
@@ -31,17 +34,28 @@ class BatchedWorld:
         self.n_envs_padded = L.rem2d_padded_envs(C.byref(self.cfg))
         self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         h = C.c_void_p()
-        _lib.check(L.rem2d_world_create(C.byref(self.cfg), self.arena.data_ptr(), nbytes, C.byref(h)))
+        self._check(L.rem2d_world_create(C.byref(self.cfg), self.arena.data_ptr(), nbytes, C.byref(h)))
         self.h = h
         self._views = {}
         self._morph_dev = None
         self.terrain = None
         self.tile_shape = -1  # -1: the library's process default
 
+    def _check(self, rc):
+        _lib.check(rc, self.wide)
+
     def close(self):
         if getattr(self, "h", None):
-            _lib.lib().rem2d_world_destroy(self.h)
+            self.L.rem2d_world_destroy(self.h)
             self.h = None
+
+    def release(self):
+        """close() and drop the device memory (arena, cached views, uploaded morphology) right away."""
+        self.close()
+        self.arena = None
+        self._views.clear()
+        self._morph_dev = None
+        self._outputs = None
 
     def __del__(self):
         try:
@@ -56,7 +70,7 @@ class BatchedWorld:
     def set_terrain(self, terrain: TerrainProfile):
         xs, ys, polys = terrain.f32()
         xs, ys, polys = np.ascontiguousarray(xs), np.ascontiguousarray(ys), np.ascontiguousarray(polys)
-        _lib.check(_lib.lib().rem2d_world_set_terrain(
+        self._check(self.L.rem2d_world_set_terrain(
             self.h, xs.ctypes.data, ys.ctypes.data, len(xs), polys.ctypes.data if len(polys) else None, len(polys),
             float(terrain.friction)))
         self.terrain = terrain
@@ -75,15 +89,15 @@ class BatchedWorld:
         for k in _lib.MORPH_FIELDS:
             setattr(m, k, dev[k].data_ptr())
         self._morph_dev = dev  # keep alive until the reset kernel has run
-        _lib.check(_lib.lib().rem2d_world_reset(self.h, C.byref(m), self._stream()))
+        self._check(self.L.rem2d_world_reset(self.h, C.byref(m), self._stream()))
         # work partition of the velocity kernel: consecutive creatures packed into tiles of <= 256 lanes with <= 64
         # joints per schedule phase (include/rem2d.h, rem2d_world_set_tiles)
         if tile_shape is not None:
-            _lib.check(_lib.lib().rem2d_world_set_tile_shape(self.h, int(tile_shape)))
+            self._check(self.L.rem2d_world_set_tile_shape(self.h, int(tile_shape)))
             self.tile_shape = int(tile_shape)
         self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
                                      self.n_envs_padded, tile_shape=self.tile_shape)
-        _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
+        self._check(self.L.rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def adopt(self, morph: Morphology, tile_shape=None):
         """Instead of reset(): the caller has filled every state field of this world (``view(name)`` for all of
@@ -92,25 +106,25 @@ class BatchedWorld:
         if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
             raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %
                              (morph.n_envs, morph.lanes, self.n_envs, self.lanes))
-        _lib.check(_lib.lib().rem2d_world_adopt(self.h))
+        self._check(self.L.rem2d_world_adopt(self.h))
         if tile_shape is not None:
-            _lib.check(_lib.lib().rem2d_world_set_tile_shape(self.h, int(tile_shape)))
+            self._check(self.L.rem2d_world_set_tile_shape(self.h, int(tile_shape)))
             self.tile_shape = int(tile_shape)
         self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
                                      self.n_envs_padded, tile_shape=self.tile_shape)
-        _lib.check(_lib.lib().rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
+        self._check(self.L.rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def set_outputs(self, reward, done, index):
         """Let the kernels also write reward / done of creature e to reward[index[e]] / done[index[e]] (population
         order; `done` is a torch.bool tensor, `index` int32 on the device).  The tensors are kept alive here."""
         self._outputs = (reward, done, index)
-        _lib.check(_lib.lib().rem2d_world_set_outputs(self.h, reward.data_ptr(), done.data_ptr(), index.data_ptr()))
+        self._check(self.L.rem2d_world_set_outputs(self.h, reward.data_ptr(), done.data_ptr(), index.data_ptr()))
 
     def step(self, n_steps=1):
-        _lib.check(_lib.lib().rem2d_world_step(self.h, int(n_steps), self._stream()))
+        self._check(self.L.rem2d_world_step(self.h, int(n_steps), self._stream()))
 
     def step_ex(self, n_steps, dt, vel_iters, pos_iters):
-        _lib.check(_lib.lib().rem2d_world_step_ex(self.h, int(n_steps), float(dt), int(vel_iters), int(pos_iters),
+        self._check(self.L.rem2d_world_step_ex(self.h, int(n_steps), float(dt), int(vel_iters), int(pos_iters),
                                                   self._stream()))
 
     # ---- zero-copy state views ----
@@ -118,7 +132,7 @@ class BatchedWorld:
         v = self._views.get(name)
         if v is None:
             off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int32()
-            _lib.check(_lib.lib().rem2d_world_field(self.h, _lib.FIELD_ID[name], C.byref(off), C.byref(cnt),
+            self._check(self.L.rem2d_world_field(self.h, _lib.FIELD_ID[name], C.byref(off), C.byref(cnt),
                                                     C.byref(dt)))
             dtype = _DTYPES[dt.value]
             nb = cnt.value * (8 if dt.value == 2 else 4)
@@ -126,8 +140,8 @@ class BatchedWorld:
             Lp = self.n_envs_padded * self.lanes
             if cnt.value == Lp:
                 v = v.view(self.n_envs_padded, self.lanes)[:self.n_envs]
-            elif cnt.value == Lp * _lib.CONTACT_SLOTS:
-                v = v.view(_lib.CONTACT_SLOTS, self.n_envs_padded, self.lanes)[:, :self.n_envs]
+            elif cnt.value == Lp * self.contact_slots:
+                v = v.view(self.contact_slots, self.n_envs_padded, self.lanes)[:, :self.n_envs]
             else:
                 v = v[:self.n_envs]
             self._views[name] = v
@@ -141,15 +155,15 @@ class BatchedWorld:
         return torch.stack(cols, dim=-1).cpu().numpy()
 
     def enable_timing(self, on=True):
-        _lib.check(_lib.lib().rem2d_world_enable_timing(self.h, 1 if on else 0))
+        self._check(self.L.rem2d_world_enable_timing(self.h, 1 if on else 0))
 
     def step_time_ms(self):
         """(device ms, steps) of the whole kernel sequence of the env-steps since the last call (tile pipeline)."""
         t, n = C.c_double(), C.c_int64()
-        _lib.check(_lib.lib().rem2d_world_step_time_ms(self.h, C.byref(t), C.byref(n)))
+        self._check(self.L.rem2d_world_step_time_ms(self.h, C.byref(t), C.byref(n)))
         return t.value, n.value
 
     def kernel_time_ms(self):
         t, n = C.c_double(), C.c_int64()
-        _lib.check(_lib.lib().rem2d_world_kernel_time_ms(self.h, C.byref(t), C.byref(n)))
+        self._check(self.L.rem2d_world_kernel_time_ms(self.h, C.byref(t), C.byref(n)))
         return t.value, n.value

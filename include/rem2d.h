@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 5 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
-                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt */
+#define REM2D_ABI_VERSION 6 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity */
 
 enum {
     REM2D_OK = 0,
@@ -48,8 +48,18 @@ enum {
 #define REM2D_FLAG_SKIP_FROZEN 8u
 
 #define REM2D_MAX_LANES 64
+/* Capacity of one body's contact bookkeeping.  Box2D has no such cap (Modular2DEnv.py:634 solves whatever touches); the
+ * library is built twice from the same source: librem2d.so with the slots below and librem2d_wide.so (-DREM2D_WIDE) with
+ * 32 pair slots / 12 solver slots, into which the host re-runs the (rare) creatures that set an overflow bit -- see
+ * gym_rem2d_amd.evaluate.run_episode.  rem2d_capacity() reports what a loaded library was built with; the state arena of
+ * a wide world is laid out for its own slot count. */
+#ifdef REM2D_WIDE
+#define REM2D_CONTACT_SLOTS 32
+#define REM2D_SOLVER_SLOTS 12
+#else
 #define REM2D_CONTACT_SLOTS 24 /* broadphase pair slots per body */
 #define REM2D_SOLVER_SLOTS 6  /* touching contacts per body that enter the solver */
+#endif
 
 typedef struct rem2d_world rem2d_world;
 
@@ -112,6 +122,8 @@ enum { REM2D_DT_F32 = 0, REM2D_DT_I32 = 1, REM2D_DT_F64 = 2 };
 
 int rem2d_abi_version(void);
 const char *rem2d_last_error(void);
+/* REM2D_CONTACT_SLOTS / REM2D_SOLVER_SLOTS of this build (either pointer may be NULL) */
+int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots);
 
 /* Bytes of device memory the caller must provide for a world of this shape. */
 size_t rem2d_state_bytes(const rem2d_world_cfg *cfg);
@@ -194,6 +206,27 @@ int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_i
 int rem2d_worlds_step(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, void *stream);
 int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                          int32_t pos_iters, void *stream);
+
+/* n_steps x Modular2D.step for a population that has been cut into STEP GROUPS (independent parts -- the reference steps
+ * every individual as an independent env, REM2D_main.py:256-267 pool.map, :362-368 the per-individual step loop -- each
+ * a set of lane-bucket worlds as in rem2d_worlds_step), every group on a stream of its own so that one group's chain of
+ * kernels runs under the others'.  One call queues the whole job: the group streams first wait for everything queued on
+ * `stream` so far (fork), then step l of EVERY group is queued before step l + 1 of any (round-robin: no group's stream
+ * runs dry while the host queues another group's train), and finally `stream` waits for every group (join).  A group
+ * whose `stream` is NULL runs on `stream` itself.  Same result as rem2d_worlds_step on every group.
+ * flags: REM2D_STEP_GRAPH -- capture the call's launches and fork / join edges into a hipGraph the first time and replay it
+ * with one hipGraphLaunch afterwards (re-captured when a world's tiles / outputs / terrain change; ignored while kernel
+ * timing is on). */
+#define REM2D_MAX_STEP_GROUPS 16
+#define REM2D_STEP_GRAPH 1u
+typedef struct {
+    rem2d_world *const *worlds; /* the group's lane-bucket worlds, <= REM2D_MAX_WORLDS_PER_STEP */
+    int32_t n_worlds;
+    void *stream;               /* hipStream_t of this group; NULL: the call's `stream` */
+} rem2d_step_group;
+int rem2d_groups_step(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, void *stream, uint32_t flags);
+int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, float dt, int32_t vel_iters,
+                         int32_t pos_iters, void *stream, uint32_t flags);
 
 /* Host-side genotype -> phenotype for L-system genomes (Encodings/LSystem.py:144-199 create, then
  * Modular2DEnv.py:517-563 create_robot with simple_module.py:147-199,231-313, circular_module.py:138-221 and

@@ -107,6 +107,8 @@ def _load(path):
         L.rem2d_oracle_kat_toi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.rem2d_oracle_kat_contact_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.rem2d_oracle_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 5
+        L.rem2d_oracle_batch_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_void_p,
+                                                C.c_void_p]
         L.rem2d_oracle_world_from_morph.restype = C.c_void_p
         L.rem2d_oracle_world_from_morph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
     return L
@@ -365,3 +367,16 @@ def batch_run(terrain, m, n_steps, n_threads=1, flags=0, trace=False):
     if rc != 0:
         raise RuntimeError("rem2d_oracle_batch_run failed: %d" % rc)
     return dict(bodies=bodies, reward=reward, done=done, fitness=fitness, trace=tr)
+
+
+def batch_window(terrain, m, settle, window, n_threads=1, flags=0):
+    """bench.py's cpu_baseline: `settle` untimed steps, then ONE continuous timed window of `window` steps of every
+    env of morphology dict m.  Returns (seconds of the window, reward [N] after it)."""
+    om, keep = make_omorph(m)
+    sec = C.c_double(0.0)
+    reward = np.zeros(om.n_envs, dtype=np.float64)
+    rc = terrain.L.rem2d_oracle_batch_window(terrain.h, C.byref(om), int(settle), int(window), int(n_threads), flags,
+                                             C.byref(sec), _ptr(reward))
+    if rc != 0:
+        raise RuntimeError("rem2d_oracle_batch_window failed: %d" % rc)
+    return sec.value, reward

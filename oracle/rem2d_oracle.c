@@ -3243,3 +3243,49 @@ int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, in
     }
     return 0;
 }
+
+/* bench.py's cpu_baseline leg: ONE continuous timed window.  Every creature of the batch is first stepped `settle` times
+ * (untimed, worlds kept), then the wall clock runs around `window` further steps of all of them (OpenMP over creatures, as
+ * in rem2d_oracle_batch_run).  *seconds_out = wall time of the window only; returns 0, or -1 on a bad batch / allocation. */
+#include <time.h>
+static double wall_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+int rem2d_oracle_batch_window(const o_terrain *t, const o_morph *m, int settle, int window, int n_threads, unsigned flags,
+                              double *seconds_out, double *reward_out) {
+    int N = m->n_envs;
+    if (m->lanes > O_MAX_BODIES || N <= 0 || !seconds_out) return -1;
+    o_world **ws = (o_world **)calloc((size_t)N, sizeof(o_world *));
+    if (!ws) return -1;
+    (void)n_threads;
+    int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (int e = 0; e < N; ++e) {
+        double reward = 0.0;
+        int done = 0;
+        ws[e] = rem2d_oracle_world_from_morph(t, m, e, flags);
+        if (!ws[e]) { __atomic_store_n(&bad, 1, __ATOMIC_RELAXED); continue; }
+        for (int step = 0; step < settle; ++step) rem2d_oracle_env_step(ws[e], &reward, &done);
+    }
+    if (!bad) {
+        const double t0 = wall_seconds();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+        for (int e = 0; e < N; ++e) {
+            double reward = 0.0;
+            int done = 0;
+            for (int step = 0; step < window; ++step) rem2d_oracle_env_step(ws[e], &reward, &done);
+            if (reward_out) reward_out[e] = reward;
+        }
+        *seconds_out = wall_seconds() - t0;
+    }
+    for (int e = 0; e < N; ++e)
+        if (ws[e]) rem2d_oracle_world_destroy(ws[e]);
+    free(ws);
+    return bad ? -1 : 0;
+}

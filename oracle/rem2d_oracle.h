@@ -32,7 +32,7 @@ extern "C" {
                                             * (round-1 form; bit-identical results, tests/test_oracle_kat.py) */
 
 #define O_MAX_BODIES 64
-#define O_MAX_BODY_CONTACTS 24
+#define O_MAX_BODY_CONTACTS 32 /* >= the wide HIP build's pair slots (include/rem2d.h REM2D_WIDE) */
 
 typedef struct o_terrain o_terrain;
 typedef struct o_world o_world;
@@ -115,6 +115,11 @@ void rem2d_oracle_circle_mass(float r, float *mass, float *I);
 int rem2d_oracle_batch_run(const o_terrain *, const o_morph *, int n_steps, int n_threads,
                            unsigned flags, float *bodies_out, double *reward_out,
                            int32_t *done_out, double *fitness_out, float *trace_out);
+
+/* bench.py's cpu_baseline leg: `settle` untimed steps of every creature (worlds kept), then ONE continuous wall-clock window
+ * around `window` further steps of all of them (OpenMP over creatures).  *seconds_out = the window's wall time. */
+int rem2d_oracle_batch_window(const o_terrain *, const o_morph *, int settle, int window, int n_threads, unsigned flags,
+                              double *seconds_out, double *reward_out);
 
 /* TOI sub-steps and forced dynamic-sweep advances (see rem2d_oracle_toi_dynamic_advances) summed over all worlds
  * that rem2d_oracle_batch_run has stepped since the last reset. */

@@ -21,9 +21,10 @@ def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "rem2d.h")).read()
     names = sorted(set(re.findall(r"\b(rem2d_[a-z_0-9]+)\s*\(", hdr)))
     assert len(names) >= 12
-    L = C.CDLL(lib.LIB_PATH)
-    for n in names:
-        assert hasattr(L, n), "librem2d.so does not export %s" % n
+    for path in (lib.LIB_PATH, lib.WIDE_LIB_PATH):
+        L = C.CDLL(path)
+        for n in names:
+            assert hasattr(L, n), "%s does not export %s" % (os.path.basename(path), n)
 
 
 def test_field_table_matches_header(lib):
@@ -35,7 +36,11 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 5
+    assert L.rem2d_abi_version() == 6
+    assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
+    # a wide world's arena is laid out for its own slot count
+    big = lib.WorldCfg(4096, 8, 0, 0)
+    assert lib.lib(wide=True).rem2d_state_bytes(C.byref(big)) > L.rem2d_state_bytes(C.byref(big))
     cfg = lib.WorldCfg(65536, 8, 0, 0)
     n = L.rem2d_state_bytes(C.byref(cfg))
     # every field is per lane / per slot / per creature: a few hundred bytes per body
@@ -48,6 +53,7 @@ def test_host_only_entry_points(lib):
     assert rc == -1 and b"lanes" in L.rem2d_last_error()
     assert L.rem2d_world_destroy(None) == 0
     assert L.rem2d_world_step(None, 1, None) == -1
+    assert L.rem2d_groups_step(None, 0, 1, None, 0) == -1 and b"step groups" in L.rem2d_last_error()
 
 
 def test_product_never_imports_oracle():

@@ -50,9 +50,10 @@ def test_cpu_baseline_times_the_gpu_legs_window(oracle):
         groups.setdefault(lanes_for(s.n_bodies), []).append(s)
     morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
     cb = bench.cpu_baseline(morphs, make_terrain(4, flat=True), 1, settle=30, window=25, budget_s=5.0)
-    assert cb["kind"] == "port" and cb["unit"] == "env-steps/s" and cb["cores"] == (os.cpu_count() or 1)
+    assert cb["kind"] == "port" and cb["is_oracle"] and cb["unit"] == "env-steps/s"
+    assert cb["cores"] == bench.host_cores()[0] <= len(os.sched_getaffinity(0))
     assert cb["value"] > 0 and cb["value_1thread"] > 0
-    assert "steps [30, " in cb["sample"] and "48 creatures" in cb["sample"]
+    assert "steps [30, " in cb["sample"] and "48 creatures" in cb["sample"] and "one continuous timed window" in cb["sample"]
     json.dumps(cb)
     # the re-laid-out batch is the same physics: 16-lane repack of a 4-lane bucket gives the oracle the same bodies
     m = morphs[0]

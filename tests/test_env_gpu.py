@@ -224,6 +224,13 @@ def test_bench_json_contract(need_gpu):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # blocks of exactly `steps` env-steps, repeated until the timed region is >= --min-time (default 1 s); value = median
+    cfg = d["config"]
+    assert cfg["blocks"] == len(cfg["blocks_ms"]) >= 1 and cfg["timed_region_s"] >= 1.0
+    import numpy as np
+    assert abs(d["ms_per_step"] * d["steps"] - float(np.median(cfg["blocks_ms"]))) < 1e-2
+    assert abs(d["value"] - cfg["creatures_total"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
@@ -243,38 +250,92 @@ def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
-    assert d["metric"].startswith("env steps/sec (whole node) at 1 024 parallel creatures")
-    assert d["config"]["envs_per_gpu"] == 512 and d["config"]["solver_errors"] == 0
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]   # the same string at every N
+    assert d["config"]["envs_per_gpu"] == 512 and d["config"]["creatures_total"] == 1024 and d["config"]["solver_errors"] == 0
+    # strong scaling: the same population split over the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--envs", "512", "--settle", "5", "--no-cpu-baseline", "--scaling", "strong", "--min-time", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["creatures_total"] == 512
+    assert d["config"]["envs_per_gpu"] == 256 and d["config"]["blocks"] == 1 and d["config"]["solver_errors"] == 0
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
                          text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
-def test_solver_overflow_is_not_silent(need_gpu):
-    """A body resting on more than REM2D_SOLVER_SLOTS (6) terrain edges loses a manifold in the solver: the evaluators
-    raise (or warn) instead of handing a wrong fitness to selection (Modular2DEnv.py:634 would solve all of them)."""
-    import pytest
-    import torch
-    from gym_rem2d_amd import _lib, synthetic
-    from gym_rem2d_amd.env import BatchedModular2D
-    from gym_rem2d_amd.evaluate import SolverOverflow, check_errors, run_episode
+def _plank_population():
+    from gym_rem2d_amd import synthetic
     m = synthetic.chain_population(4, 2, "left")
     hx = m.arrays["hx"].reshape(4, m.lanes)
     hy = m.arrays["hy"].reshape(4, m.lanes)
     ang = m.arrays["angle"].reshape(4, m.lanes)
     hx[2, 0], hy[2, 0], ang[2, 0] = 0.1, 2.2, np.float32(np.pi / 2)   # creature 2: a 4.4 m plank lying across ~9 edges
+    return m
+
+
+def test_solver_overflow_falls_back_to_the_wide_build(need_gpu, oracle, flat_terrain):
+    """A body resting on more than REM2D_SOLVER_SLOTS (6) terrain edges loses a manifold in the default build's solver
+    (Modular2DEnv.py:634 would solve all of them: Box2D has no cap).  run_episode re-evaluates the flagged creature in
+    the wide build (32 pair / 12 solver slots): every individual gets the oracle's fitness, bit for bit; the strict modes
+    still raise / warn instead of handing a wrong fitness to selection."""
+    import pytest
+    import torch
+    from conftest import oracle_terrain
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import SolverOverflow, check_errors, run_episode
+    from gym_rem2d_amd.world import BatchedWorld
+    m = _plank_population()
+    assert _lib.capacity() == (24, 6) and _lib.capacity(wide=True) == (32, 12)
+    ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), m.as_dict(), 150, n_threads=2, flags=oracle.FLAG_CONTINUOUS)
     env = BatchedModular2D(flat=True)
     env.reset_morphology(m)
+    fit = run_episode(env, max_steps=150)                                   # default: on_error="fallback"
+    assert env.last_overflow == [2]
+    assert np.array_equal(fit.cpu().numpy(), ref["fitness"])
+    env.reset_morphology(m)
     with pytest.raises(SolverOverflow) as ei:
-        run_episode(env, max_steps=150)
+        run_episode(env, max_steps=150, on_error="raise")
     assert ei.value.indices == [2] and ei.value.codes[0] & _lib.ERR_SOLVER_OVERFLOW
     env.reset_morphology(m)
     with pytest.warns(UserWarning):
         fit = run_episode(env, max_steps=150, on_error="warn")
     assert fit.shape == (4,) and bool(check_errors(env, "ignore")[2]) and int(check_errors(env, "ignore").sum()) == 1
     env.close()
+    # the wide build on its own: the plank's whole state == oracle (more than 6 touching manifolds on one body)
+    w = BatchedWorld(m.n_envs, m.lanes, flags=_lib.FLAG_CONTINUOUS, wide=True)
+    w.set_terrain(flat_terrain)
+    w.reset(m)
+    w.step(150)
+    assert np.array_equal(w.bodies(), ref["bodies"]) and int(w.view("err").max()) == 0
+    assert int((w.view("cinfo")[:, 2, 0] & 0xff).gt(0).sum()) > 6          # touching manifolds on the plank
+    assert w.view("cedge").shape[0] == 32
+    w.close()
     torch.cuda.synchronize()
+
+
+def test_wide_build_is_the_same_engine(need_gpu, oracle, rough_terrain):
+    """librem2d_wide.so is the same source with more slots: on populations that fit the default build it gives the same
+    bits (== oracle), in one merged launch over several lane buckets and in the 256-lane tile shape."""
+    from conftest import oracle_terrain
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(96))
+    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS, wide=True)
+    env.reset_specs(specs)
+    env.step(120)
+    ot = oracle_terrain(oracle, rough_terrain)
+    for w, idx in env.worlds:
+        part = Morphology.from_specs([specs[e] for e in idx.cpu().tolist()], w.lanes)
+        r = oracle.batch_run(ot, part.as_dict(), 120, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+        assert w.wide and np.array_equal(w.bodies(), r["bodies"])
+        assert np.array_equal(w.view("fitness").cpu().numpy(), r["fitness"])
+    assert int(env.errors().max()) == 0
+    env.close()
 
 
 def test_state_dump_for_external_viewers(need_gpu, tmp_path):

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Reads a rocprofv3 --kernel-trace CSV directory and reports, for the last launches of the run (the timed region), how
+many kernels ran concurrently on average (sum of kernel durations / wall span), per queue launch counts and the
+per-kernel average duration.   python3 tools/trace_overlap.py <dir> [n_last]"""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    files = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if "rem2d_" in r["Kernel_Name"] and "reset" not in r["Kernel_Name"]:
+                    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""),
+                                 r.get("Queue_Id", "?")))
+    rows.sort()
+    rows = rows[-n_last:]
+    if not rows:
+        print("no rem2d kernels in trace")
+        return
+    span = max(r[1] for r in rows) - min(r[0] for r in rows)
+    busy = sum(r[1] - r[0] for r in rows)
+    print("last %d rem2d dispatches: wall span %.3f ms, sum of kernel durations %.3f ms -> %.2f kernels in flight on average"
+          % (len(rows), span / 1e6, busy / 1e6, busy / span))
+    # time with k kernels in flight
+    ev = []
+    for s, e, _, _ in rows:
+        ev.append((s, 1))
+        ev.append((e, -1))
+    ev.sort()
+    hist = defaultdict(int)
+    cur, last = 0, ev[0][0]
+    for t, dlt in ev:
+        hist[cur] += t - last
+        cur += dlt
+        last = t
+    print("time share by number of kernels in flight: " + ", ".join("%d: %.1f%%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
+    per = defaultdict(list)
+    q = defaultdict(int)
+    for s, e, n, qu in rows:
+        per[n].append(e - s)
+        q[qu] += 1
+    for n, v in sorted(per.items()):
+        print("  %-50s n=%4d avg %.4f ms max %.4f ms" % (n[:50], len(v), sum(v) / len(v) / 1e6, max(v) / 1e6))
+    print("dispatches per queue: " + ", ".join("%s: %d" % kv for kv in sorted(q.items())))
+
+
+if __name__ == "__main__":
+    main()
