@@ -212,31 +212,31 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
     ot = O.Terrain(xs, ys, polys if len(polys) else None, terrain.friction)
     cores, quota = host_cores()
     total = sum(m.n_envs for m in morphs)
-    want = min(total, max(256, 48 * cores), 8192)      # >= 48 creatures per host thread (creature costs vary a lot)
     lanes = max(m.lanes for m in morphs)
-    parts = []
-    for m in morphs:
-        t = min(m.n_envs, max(1, int(round(want * m.n_envs / total))))
-        parts.append(_repack(m.take(np.linspace(0, m.n_envs - 1, t).astype(np.int64)), lanes))
-    sample = {"n_envs": sum(p["n_envs"] for p in parts), "lanes": lanes}
-    for k in parts[0]:
-        if k not in ("n_envs", "lanes"):
-            sample[k] = np.concatenate([p[k] for p in parts])
-    n = sample["n_envs"]
-    # one thread first (a slice of the sample): it also sizes the window of the all-thread leg to the budget
-    n1 = max(8, min(n, 32))
-    idx = np.linspace(0, n - 1, n1).astype(np.int64)
-    lanes_idx = (idx[:, None] * lanes + np.arange(lanes)[None, :]).reshape(-1)
-    sub = {"n_envs": n1, "lanes": lanes}
-    for k, v in sample.items():
-        if k not in ("n_envs", "lanes"):
-            sub[k] = v[lanes_idx]
+
+    def sample_of(want):
+        parts = []
+        for m in morphs:
+            t = min(m.n_envs, max(1, int(round(want * m.n_envs / total))))
+            parts.append(_repack(m.take(np.linspace(0, m.n_envs - 1, t).astype(np.int64)), lanes))
+        smp = {"n_envs": sum(p["n_envs"] for p in parts), "lanes": lanes}
+        for k in parts[0]:
+            if k not in ("n_envs", "lanes"):
+                smp[k] = np.concatenate([p[k] for p in parts])
+        return smp
+    # one thread first (a small slice): it also sizes the all-thread leg to the budget
+    sub = sample_of(min(total, 32))
+    n1 = sub["n_envs"]
     w1 = max(50, min(window, 200))
     t1, _ = O.batch_window(ot, sub, settle, w1, n_threads=1, flags=flags)
     one_thread = n1 * w1 / max(t1, 1e-6)
-    # all threads: window sized so that settle + window stays within the budget at ~cores x the 1-thread rate
-    per_step = n / max(one_thread * cores * 0.7, 1.0)     # seconds per step of the whole sample (estimate)
-    window = int(max(20, min(max(window, 100), budget_s / per_step - settle)))
+    # all threads: about budget_s seconds of CPU wall time in all (settle + window), >= 48 creatures per thread (creature
+    # costs vary a lot), at most 8192 worlds (~0.4 MB each); the window is the GPU leg's, stretched to 100..400 steps
+    window = int(max(100, min(window, 400)))
+    est_rate = one_thread * cores * 0.7
+    want = int(budget_s * est_rate / (settle + window))
+    sample = sample_of(min(total, max(256, 48 * cores, min(want, 8192))))
+    n = sample["n_envs"]
     tw, _ = O.batch_window(ot, sample, settle, window, n_threads=cores, flags=flags)
     all_threads = n * window / max(tw, 1e-6)
     return {"value": all_threads, "unit": "env-steps/s", "cores": cores, "kind": "port", "is_oracle": True,

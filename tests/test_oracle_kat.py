@@ -503,3 +503,70 @@ def test_solve_toi_static_body_bookkeeping_is_transparent(oracle):
             assert np.array_equal(a["fitness"], b["fitness"])
             total_events += events
     assert total_events > 500      # the populations do exercise SolveTOI
+
+
+def test_box2d_manual_hello_world_trace(oracle):
+    """An external vector, RECALLED (not fetched: no network, no Box2D in the image): the position trace the Box2D v2.3
+    manual prints for its "Hello Box2D" program (section 2.4) -- ground box with half-extents (50, 10) centred at (0, -10),
+    a dynamic 1 x 1 half-extent box at (0, 4), density 1, gravity (0, -10), 60 steps of Step(1/60, 6, 2), "%4.2f %4.2f
+    %4.2f" of x, y, angle after every step: it starts 0.00 4.00 0.00 / 0.00 3.99 0.00 / 0.00 3.98 0.00, passes
+    0.00 1.25 0.00 / 0.00 1.13 0.00 / 0.00 1.01 0.00 at the landing and rests at 1.01 (= half-height + linearSlop 0.005 +
+    the polygon skin).  The oracle's engine -- b2CollidePolygons against a static polygon, (6, 2) iterations, SolveTOI as in
+    b2World's defaults -- prints the same lines; with continuous physics off the landing line reads 1.00 instead."""
+    xs = np.array([-60.0, 60.0], dtype=np.float32)           # (the mandatory edge terrain, far away from the scene)
+    ys = np.array([-100.0, -100.0], dtype=np.float32)
+    ground = np.array([[[-50, -20], [50, -20], [50, 0], [-50, 0]]], dtype=np.float32)
+    for flags in (0, oracle.FLAG_CONTINUOUS):
+        t = oracle.Terrain(xs, ys, ground, friction=0.9)
+        w = oracle.World(t, flags)
+        w.add_box(1.0, 1.0, 0.0, 4.0, 0.0)
+        st = np.zeros(8, dtype=np.float32)
+        lines = []
+        for _ in range(60):
+            w.step(1.0 / 60, 6, 2)
+            oracle.lib().rem2d_oracle_get_bodies(w.h, st.ctypes.data)
+            lines.append("%4.2f %4.2f %4.2f" % (abs(st[0]), st[1], abs(st[2])))
+        assert lines[:3] == ["0.00 4.00 0.00", "0.00 3.99 0.00", "0.00 3.98 0.00"]
+        k = lines.index("0.00 1.25 0.00")
+        if flags & oracle.FLAG_CONTINUOUS:
+            # b2World's default (continuousPhysics on), i.e. what the manual ran: SolveTOI stops the box AT the surface
+            assert lines[k:k + 3] == ["0.00 1.25 0.00", "0.00 1.13 0.00", "0.00 1.01 0.00"]
+            assert set(lines[k + 2:]) == {"0.00 1.01 0.00"}      # at rest on the ground box for the rest of the second
+        else:
+            # without SolveTOI the discrete step sinks in (1.00) before the position solver pushes it back out: this
+            # line of the manual is a check of the TOI path, not only of the integrator
+            assert lines[k:k + 3] == ["0.00 1.25 0.00", "0.00 1.13 0.00", "0.00 1.00 0.00"] and lines[-1] == "0.00 1.01 0.00"
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The oracle's C source compiled with -fsanitize=address,undefined (CPU build only: GPU sanitizers are not available on
+    this pool) runs creatures with contacts, joints at their limits, TOI events and hardcore boxes without a report."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "librem2d_oracle_asan.so")
+    src = os.path.join(ROOT, "oracle", "rem2d_oracle.c")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-o", so, src, "-lm"])
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "O._SO = %r\n"
+        "from gym_rem2d_amd import make_terrain, synthetic\n"
+        "from gym_rem2d_amd.compiler import Morphology\n"
+        "for hard, maker in ((False, synthetic.lsystem_specs), (True, synthetic.cppn_specs)):\n"
+        "    t = make_terrain(4, hardcore=hard)\n"
+        "    xs, ys, polys = t.f32()\n"
+        "    ot = O.Terrain(xs, ys, polys if len(polys) else None, t.friction)\n"
+        "    m = Morphology.from_specs(maker(range(24)), 32)\n"
+        "    r = O.batch_run(ot, m.as_dict(), 150, n_threads=2, flags=O.FLAG_CONTINUOUS)\n"
+        "    assert np.isfinite(r['bodies']).all()\n"
+        "    sec, _ = O.batch_window(ot, m.as_dict(), 5, 5, n_threads=2, flags=O.FLAG_CONTINUOUS)\n"
+        "print('sanitized oracle OK')\n" % (ROOT, so))
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitized oracle OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
