@@ -348,6 +348,27 @@ int rem2d_cpu_worlds_step(rem2d_cpu_world *const *worlds, int32_t n_worlds, int3
     return rem2d_cpu_worlds_step_ex(worlds, n_worlds, n_steps, (float)(1.0 / FPS), 6 * 30, 2 * 30, stream);
 }
 /* timing of GPU launches: nothing to report */
+/* rem2d_groups_step: the step groups of a population, one after the other (streams and graphs mean nothing on the host) */
+int rem2d_cpu_groups_step_ex(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, float dt, int32_t vel_iters,
+                             int32_t pos_iters, void *stream, uint32_t flags) {
+    (void)flags;
+    if (!groups || n_groups <= 0) return c_fail(REM2D_E_INVALID, "no step groups");
+    if (n_groups > REM2D_MAX_STEP_GROUPS) return c_fail(REM2D_E_INVALID, "too many step groups");
+    for (int g = 0; g < n_groups; ++g) {
+        int rc = rem2d_cpu_worlds_step_ex((rem2d_cpu_world *const *)groups[g].worlds, groups[g].n_worlds, n_steps, dt, vel_iters,
+                                          pos_iters, stream);
+        if (rc != REM2D_OK) return rc;
+    }
+    return REM2D_OK;
+}
+int rem2d_cpu_groups_step(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, void *stream, uint32_t flags) {
+    return rem2d_cpu_groups_step_ex(groups, n_groups, n_steps, (float)(1.0 / FPS), 6 * 30, 2 * 30, stream, flags);
+}
+int rem2d_cpu_capacity(int32_t *contact_slots, int32_t *solver_slots) {
+    if (contact_slots) *contact_slots = REM2D_CONTACT_SLOTS;
+    if (solver_slots) *solver_slots = REM2D_SOLVER_SLOTS;
+    return REM2D_OK;
+}
 int rem2d_cpu_world_enable_timing(rem2d_cpu_world *w, int32_t on) { (void)on; return w ? REM2D_OK : c_fail(REM2D_E_INVALID, "world is NULL"); }
 int rem2d_cpu_world_kernel_time_ms(rem2d_cpu_world *w, double *total_ms, int64_t *launches) {
     if (total_ms) *total_ms = 0.0;
