@@ -18,6 +18,7 @@ FLAG_CONTINUOUS = 1
 FLAG_SLEEP_RESET_ALWAYS = 2
 FLAG_NO_SLEEP = 4
 FLAG_SKIP_FROZEN = 8
+FLAG_RETILE = 16
 
 CONTACT_SLOTS = 24
 MAX_WORLDS_PER_STEP = 8

@@ -238,6 +238,20 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         delete w;
         return fail(REM2D_E_HIP, std::string("hipMemset(scratch): ") + hipGetErrorString(e));
     }
+    // creature order of the post kernel (rem2d_pipeline.h, "Dynamic re-tiling"): both halves start as the identity
+    {
+        std::vector<int> ord((size_t)2 * L.Np + 4, 0);
+        for (int i = 0; i < L.Np; ++i) ord[i] = ord[(size_t)L.Np + i] = i;
+        w->S.order = nullptr;
+        e = hipMalloc((void **)&w->S.order, ord.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(w->S.order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (w->S.order) (void)hipFree(w->S.order);
+            (void)hipFree(w->S.scr);
+            delete w;
+            return fail(REM2D_E_HIP, std::string("hipMalloc(order): ") + hipGetErrorString(e));
+        }
+    }
     // default tiles of the velocity kernel.  The joints of one schedule phase of a creature are a matching of its tree
     // (<= lanes / 2 of them), so 128 / lanes creatures never have more than 64 joints in a phase;
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
@@ -257,6 +271,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         int rc = rem2d_world_set_tiles(w, ts.data(), (int32_t)ts.size() - 1);
         if (rc != REM2D_OK) {
             (void)hipFree(w->S.scr);
+            (void)hipFree(w->S.order);
             delete w;
             return rc;
         }
@@ -448,6 +463,7 @@ extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (w->evFork) (void)hipEventDestroy(w->evFork);
     if (w->evJoin) (void)hipEventDestroy(w->evJoin);
     if (w->S.scr) (void)hipFree(w->S.scr);
+    if (w->S.order) (void)hipFree(w->S.order);
     if (w->tilesDev) (void)hipFree(w->tilesDev);
     if (w->terrainBuf) (void)hipFree(w->terrainBuf);
     delete w;

@@ -29,10 +29,15 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     const int sub = lane & (K - 1);
     const unsigned Lp = S.Lp;
     if (gl == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
+    // creature order of the post kernel: what post wrote in the last step becomes what it reads in this one
+    if (S.flags & REM2D_FLAG_RETILE) {
+        if (gl < S.Np) S.order[gl] = S.order[S.Np + gl];
+        if (gl == 0) { S.order[2 * S.Np] = 0; S.order[2 * S.Np + 1] = 0; }
+    }
     if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // evaluate() has left its loop for every creature of this wavefront
         if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) {
             const unsigned mb = (unsigned)SCR_MISC_BASE * Lp + gl;
-            SW(mb, 0) = __int_as_float(0); // nothing to solve for the velocity kernel; post and the TOI kernels skip too
+            SW(mb, 0) = __int_as_float(0x200); // nothing to solve for the velocity kernel; 0x200: post and the TOI kernels skip this creature too
             return;
         }
     }
@@ -204,16 +209,51 @@ DEV int wave_or(int v) {
 // ---------------------------------------------------------------------------------------------------
 // post: position integration / iterations, sleep, broadphase refresh, bookkeeping
 // ---------------------------------------------------------------------------------------------------
+// Dynamic re-tiling.  The position iterations are bimodal: most creatures pass Box2D's tolerance test after one or two
+// iterations, 10-15 % (a joint at its limit pressed against the ground) never pass it and use all of them -- and they are
+// the same creatures from step to step.  A wavefront runs as many iterations as its slowest creature, and with the
+// creatures in morphology order 60-78 % of the wavefronts hold one.  Creatures are independent and every per-lane access
+// goes through `gl`, so the wavefronts of this kernel may take the creatures in ANY order: slot s of the launch (lane
+// group s of the grid) handles creature order[s].  Every step the kernel deals the creatures out again for the next one
+// -- those that used every iteration from the FRONT of the order (their wavefronts are the long ones: they must be
+// dispatched first), the others from the back (one atomic per wavefront and class) -- so that ~12 % of the wavefronts
+// run 60 iterations instead of ~70 %.  Same arithmetic on the same operands: same bits, whatever order the atomics
+// produce.  Measured (profiles/r03_retile.txt): -34 % VALU wave-instructions in this kernel (61.9 -> 41.1 M per launch),
+// but a wavefront of eight such creatures with different periods runs a contact AND a joint section in every tick, so
+// the slowest wavefront -- the kernel's duration -- gets longer: +4.4 % env-steps/s where the chip's instruction issue
+// is the limit (131 072 creatures per GPU, config 5's share), -5 % where the chain of kernels is (65 536).  Hence a
+// property of the world (REM2D_FLAG_RETILE) that the host sets for large populations.
+DEV void post_place(const State &S, int lane, int K, unsigned env, bool leader, bool slow) {
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (WAVE - lane));
+    const unsigned long long mf = __ballot(leader && !slow), ms = __ballot(leader && slow);
+    int bf = 0, bs = 0;
+    if (lane == 0) {
+        if (mf) bf = atomicAdd(&S.order[2 * S.Np], __popcll(mf));
+        if (ms) bs = atomicAdd(&S.order[2 * S.Np + 1], __popcll(ms));
+    }
+    bf = __shfl(bf, 0); bs = __shfl(bs, 0);
+    if (leader) {
+        const int pos = slow ? bs + __popcll(ms & below) : (int)S.Np - 1 - (bf + __popcll(mf & below));
+        S.order[S.Np + pos] = (int)env;
+    }
+}
 template <int K>
 DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
     const int lane = threadIdx.x;
-    const unsigned gl = block * WAVE + lane;
-    const unsigned env = gl / K;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
+    const unsigned slot = (block * WAVE + lane) / K;
+    const bool retile = (S.flags & REM2D_FLAG_RETILE) != 0;
+    const unsigned env = retile ? (unsigned)S.order[slot] : slot; // the creature this lane group handles in this step
+    const unsigned gl = env * K + sub;
     const unsigned Lp = S.Lp;
-    if (S.flags & REM2D_FLAG_SKIP_FROZEN) {
-        if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) return; // pre skipped this wavefront too
+    const int misc = __float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 0));
+    // REM2D_FLAG_SKIP_FROZEN: pre skips a wavefront (in ITS order) whose creatures have all finished and marks them;
+    // those creatures are nobody's business in this step, whichever wavefront of this kernel they ride in
+    const bool skipped = (misc & 0x200) != 0;
+    if (__all(skipped ? 1 : 0)) {
+        if (retile) post_place(S, lane, K, env, sub == 0, false);
+        return;
     }
 
     const int shape = LI(L_SHAPE);
@@ -230,7 +270,6 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     const int limitState = LI(L_JLIMIT);
     const float mA = __shfl(mB, pl), iA = __shfl(iB, pl);
     const int nRounds = wave_max(jround) + 1;
-    const int misc = __float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 0));
     const int nTouch = misc & 0xff;
     const int envAwake = (misc >> 8) & 1;
     int err = 0, lastPosIters = EI(E_POSITERS);
@@ -313,6 +352,10 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
             }
         }
     }
+    int envErr = group_or<K>(err);
+    const float rootx = __shfl(px, base);
+    if (retile) post_place(S, lane, K, env, sub == 0, envAwake && lastPosIters >= A.posIters && A.posIters > 2);
+    if (skipped) return; // (a creature pre left alone: nothing of it changes in this step)
     if (A.defer) { // continuous physics: the TOI kernel needs the sweep start and finishes the step
         const unsigned wb = (unsigned)SCR_SWEEP_BASE * Lp + gl;
         SW(wb, 0) = c0x; SW(wb, 1) = c0y; SW(wb, 2) = a0;
@@ -320,13 +363,12 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     LF(L_PX) = px; LF(L_PY) = py; LF(L_ANG) = ang; LF(L_VX) = vx; LF(L_VY) = vy; LF(L_W) = w;
     LF(L_SLEEPT) = sleepT; LI(L_AWAKE) = awake;
     LI(L_CCOUNT) = cCount;
-    int envErr = group_or<K>(err);
     if (sub == 0) {
         if (h > 0.0f) EF(E_INVDT0) = inv_dt;
         if (envErr) EI(E_ERR) = EI(E_ERR) | envErr;
         EI(E_POSITERS) = lastPosIters;
     }
-    if (!A.defer) env_bookkeeping(S, env, sub, __shfl(px, base));
+    if (!A.defer) env_bookkeeping(S, env, sub, rootx);
     // continuous physics: the TOI scan of this body, with its pose and sweep start still in registers (it was a kernel
     // of its own: one launch, one grid of early-exits and a round trip of the sweep start through HBM less per step)
     else if (A.defer == 2) toi_scan_lane(S, T, A.dt, gl, env, sub, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);

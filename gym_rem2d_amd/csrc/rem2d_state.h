@@ -81,6 +81,10 @@ struct State {
     float *scr;                                // handle-owned: manifolds [KT][SCR_WORDS][Lp] + overflow constraints
     int *toiWork;                              // handle-owned: [0] count, [16..16+Lp) bodies that need the full TOI solve
     const int *tiles;                          // handle-owned: tile t of the velocity kernel = creatures [tiles[t], tiles[t+1])
+    // handle-owned: creature order of the post kernel (dynamic re-tiling, rem2d_pipeline.h): [0, Np) the order post reads
+    // in this step (slot -> creature), [Np, 2 Np) the order post writes for the next step, [2 Np] / [2 Np + 1] how many
+    // creatures have been placed from the front / from the back of the latter
+    int *order;
     // optional, caller-owned (rem2d_world_set_outputs): reward / done of creature e also go to outReward[outIndex[e]] /
     // outDone[outIndex[e]] -- the population-order arrays of a population that lives in several worlds
     float *outReward;

@@ -73,6 +73,8 @@ def group_streams(device, n):
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
     BIG_POPULATION = 160000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
+    RETILE_POPULATION = 98304   # ... from which dealing the creatures to the position kernel's wavefronts anew every step
+                                # (REM2D_FLAG_RETILE) pays: +4.4 % at 131 072, -5 % at 65 536 (profiles/r03_retile.txt)
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
@@ -184,6 +186,9 @@ class BatchedModular2D:
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
                 shape = 1
         self._tile_shape_used = shape
+        retile = os.environ.get("REM2D_RETILE")
+        retile = (n_envs >= self.RETILE_POPULATION and not all(_uniform(m) for m, _ in batches)) if retile is None else retile == "1"
+        self._world_flags = (self.flags | _lib.FLAG_RETILE) if retile else (self.flags & ~_lib.FLAG_RETILE)
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
@@ -206,7 +211,7 @@ class BatchedModular2D:
                     pieces.append((g, mem[lo:lo + per]))
             for g, mem in pieces:
                 part = morph if len(mem) == morph.n_envs else morph.take(mem)
-                w = BatchedWorld(part.n_envs, part.lanes, self.flags, self.device, wide=self.wide)
+                w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide)
                 w.set_terrain(self._terrain())
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
@@ -329,7 +334,7 @@ class BatchedModular2D:
                 self._inactive.update(wis)
                 continue
             part = Morphology.concat([self._world_morph[wi].take(k.cpu().numpy()) for wi, k in zip(wis, keeps) if k.numel()])
-            nw = BatchedWorld(n_keep, lanes, self.flags, self.device, wide=self.wide)
+            nw = BatchedWorld(n_keep, lanes, self._world_flags, self.device, wide=self.wide)
             nw.set_terrain(self._terrain())
             for name in _lib.FIELDS:
                 dst = nw.view(name)

@@ -46,6 +46,12 @@ enum {
  * > ENV_LENGTH).  With this flag a wavefront whose creatures are ALL in that state (REM2D_F_FROZEN) is not
  * stepped any more; fitness is unaffected, the bodies of such creatures simply stop where they were. */
 #define REM2D_FLAG_SKIP_FROZEN 8u
+/* Launch shape, no effect on results: the position-iteration kernel deals the creatures to its wavefronts anew in every
+ * step -- those that used all 60 position iterations in the last step (the same ~12 % from step to step) share wavefronts
+ * instead of keeping 70 % of them busy for 60 iterations.  A third fewer wave-instructions in that kernel but a longer
+ * slowest wavefront: pays where instruction issue limits the step (>~100 000 creatures per GPU), costs where the chain
+ * of kernels does.  gym_rem2d_amd.env.BatchedModular2D sets it by population size. */
+#define REM2D_FLAG_RETILE 16u
 
 #define REM2D_MAX_LANES 64
 /* Capacity of one body's contact bookkeeping.  Box2D has no such cap (Modular2DEnv.py:634 solves whatever touches); the

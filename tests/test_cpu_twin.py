@@ -122,11 +122,12 @@ def test_twin_call_order_and_argument_errors():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,steps", [(0, (0, 1, 30, 120)), (1, (0, 1, 30, 120)), (1 | 2, (40, 160)), (1 | 4, (40, 160)),
-                                         (1 | 8, (60, 90, 150, 100))])
+                                         (1 | 8, (60, 90, 150, 100)), (1 | 8 | 16, (60, 90, 150, 100))])
 def test_same_call_sequence_same_arena(gpu, flags, steps):
     """The drop-in statement at the boundary: one sequence of ABI calls, two libraries, equal state fields -- discrete
     and continuous physics, both sleep variants, and REM2D_FLAG_SKIP_FROZEN (8: wavefronts whose creatures all have a
-    final fitness stop being stepped, in both libraries at the same step)."""
+    final fitness stop being stepped, in both libraries at the same step), the latter also with REM2D_FLAG_RETILE (16: a launch
+    shape of the HIP library that the twin ignores -- the arenas must not show it)."""
     from gym_rem2d_amd import make_terrain
     from gym_rem2d_amd.world import BatchedWorld
     T = _twin()

@@ -292,6 +292,37 @@ def test_full_size_chain8(gpu, oracle, flat_terrain):
     env.close()
 
 
+@pytest.mark.parametrize("skip_frozen", [False, True])
+def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_frozen):
+    """REM2D_FLAG_RETILE: the position-iteration kernel deals the creatures to its wavefronts anew in every step (those that
+    used all 60 iterations first; the order comes out of atomics and differs from run to run).  Creatures are independent:
+    poses, velocities, sleep state, reward, fitness and step counts equal the oracle's in every bit, also together with
+    REM2D_FLAG_SKIP_FROZEN (wavefronts of pre whose creatures have all finished are skipped; post must leave exactly those
+    creatures alone, whichever of its wavefronts they ride in)."""
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    specs = [s for s in synthetic.lsystem_specs(range(300), mutate_odd=True) if s.n_bodies <= 8]
+    morph = Morphology.from_specs(specs, 8)
+    flags = _lib.FLAG_CONTINUOUS | _lib.FLAG_RETILE | (_lib.FLAG_SKIP_FROZEN if skip_frozen else 0)
+    T = 420 if skip_frozen else 240     # (long enough for whole wavefronts of 8 creatures to have finished)
+    w, snaps = _run_gpu(gpu, morph, rough_terrain, [1, 59, T - 60], flags)
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+    assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+    assert int(w.view("err").max()) == 0
+    order = w.view("positers").cpu().numpy()
+    assert (order == 60).any() and (order < 60).any()          # both classes of creatures occur
+    if not skip_frozen:
+        assert np.array_equal(snaps[-1], ref["bodies"])
+        assert np.array_equal(w.view("reward").cpu().numpy(), ref["reward"].astype(np.float32))
+        assert bool((w.view("steps") == T).all())
+    else:
+        # creatures of skipped wavefronts stop where they were; the others are the oracle's
+        frozen = w.view("frozen").cpu().numpy() != 0
+        moved = w.view("steps").cpu().numpy() == T
+        assert frozen.any() and np.array_equal(snaps[-1][moved], ref["bodies"][moved]) and (moved | frozen).all()
+    w.close()
+
+
 def test_determinism(gpu, rough_terrain):
     morph = _populations()["lsystem_k16"]
     _, a = _run_gpu(gpu, morph, rough_terrain, [150])
