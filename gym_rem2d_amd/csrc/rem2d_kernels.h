@@ -528,8 +528,9 @@ __global__ __launch_bounds__(WAVE, 2) void rem2d_step_multi_kernel(Batch B, Step
 // =====================================================================================
 // the scan for one body (its final pose of the discrete step in registers or freshly loaded): invalidate the TOI flags of
 // its pairs, apply the exact early-outs, then either queue the body for the TOI solve or -- for a root -- finish the step
-DEV void toi_scan_lane(const State &S, const Terrain &T, float dt, unsigned gl, unsigned env, int sub, int shape, float px,
-                       float py, float ang, float c0x, float c0y, float a0, float hx, float hy, int awake, int cCount) {
+// true: the body has a pair the exact early-outs cannot rule out -> it needs the TOI solve (solve_toi_lane)
+DEV bool toi_scan_heavy(const State &S, const Terrain &T, float dt, unsigned gl, int shape, float px, float py, float ang,
+                        float c0x, float c0y, float a0, float hx, float hy, int awake, int cCount) {
     const unsigned Lp = S.Lp;
     bool heavy = false;
     if (shape != SHAPE_NONE && dt > 0.0f) {
@@ -550,6 +551,11 @@ DEV void toi_scan_lane(const State &S, const Terrain &T, float dt, unsigned gl, 
             heavy = !toi_far_apart(pA, pB, sw, shape, hx, hy, coreR);
         }
     }
+    return heavy;
+}
+DEV void toi_scan_lane(const State &S, const Terrain &T, float dt, unsigned gl, unsigned env, int sub, int shape, float px,
+                       float py, float ang, float c0x, float c0y, float a0, float hx, float hy, int awake, int cCount) {
+    const bool heavy = toi_scan_heavy(S, T, dt, gl, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
     if (heavy) {
         int slot = atomicAdd(&S.toiWork[0], 1);
         S.toiWork[16 + slot] = (int)gl;
@@ -571,6 +577,24 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
     toi_scan_lane(S, T, A.dt, gl, env, sub, LI(L_SHAPE), LF(L_PX), LF(L_PY), LF(L_ANG), SW(wb, 0), SW(wb, 1), SW(wb, 2),
                   LF(L_HX), LF(L_HY), LI(L_AWAKE), LI(L_CCOUNT));
 }
+// the TOI solve of one body (lane gl of the world) by the G lanes that carry it, then the step's bookkeeping if it is a root
+template <int K>
+DEV void toi_heavy_one(const State &S, const Terrain &T, const StepArgs &A, unsigned gl, ToiShared &ts, int sub, int G) {
+    const unsigned env = gl / K;
+    const int shape = LI(L_SHAPE);
+    const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
+    LaneBody B;
+    B.px = LF(L_PX); B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
+    B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
+    B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
+                       SW(wb, 2), B, ts, (int)threadIdx.x, sub, G);
+    if (sub != 0) return; // the body's other lanes hold the same result
+    LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
+    LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
+    if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
+    if (B.err) atomicOr(&EI(E_ERR), B.err);
+    if ((gl & (K - 1)) == 0) env_bookkeeping(S, env, 0, B.px);
+}
 template <int K>
 DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, ToiShared &ts) {
     // Bodies per wavefront: the lanes of a wavefront run the event loop in lockstep -- every b2TimeOfImpact any lane needs at
@@ -587,21 +611,7 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     const unsigned sub = threadIdx.x & (G - 1), slot = threadIdx.x / G;
     const unsigned idx = block * per + slot;
     if (slot >= per || idx >= queued) return;
-    const unsigned gl = (unsigned)S.toiWork[16 + idx];
-    const unsigned env = gl / K;
-    const int shape = LI(L_SHAPE);
-    const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;
-    LaneBody B;
-    B.px = LF(L_PX); B.py = LF(L_PY); B.ang = LF(L_ANG); B.vx = LF(L_VX); B.vy = LF(L_VY); B.w = LF(L_W);
-    B.sleepT = LF(L_SLEEPT); B.awake = LI(L_AWAKE); B.cCount = LI(L_CCOUNT); B.err = 0; B.events = 0;
-    B = solve_toi_lane(S, T, gl, shape, LF(L_HX), LF(L_HY), LF(L_INVM), LF(L_INVI), A.dt, A.velIters, SW(wb, 0), SW(wb, 1),
-                       SW(wb, 2), B, ts, (int)threadIdx.x, (int)sub, (int)G);
-    if (sub != 0) return; // the body's other lanes hold the same result
-    LF(L_PX) = B.px; LF(L_PY) = B.py; LF(L_ANG) = B.ang; LF(L_VX) = B.vx; LF(L_VY) = B.vy; LF(L_W) = B.w;
-    LF(L_SLEEPT) = B.sleepT; LI(L_AWAKE) = B.awake; LI(L_CCOUNT) = B.cCount;
-    if (B.events > 0) atomicAdd(&EI(E_TOIEVENTS), B.events);
-    if (B.err) atomicOr(&EI(E_ERR), B.err);
-    if ((gl & (K - 1)) == 0) env_bookkeeping(S, env, 0, B.px);
+    toi_heavy_one<K>(S, T, A, (unsigned)S.toiWork[16 + idx], ts, (int)sub, (int)G);
 }
 
 __global__ __launch_bounds__(WAVE) void rem2d_toi_scan_multi_kernel(Batch B, StepArgs A) {

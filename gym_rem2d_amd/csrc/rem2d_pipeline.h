@@ -237,8 +237,10 @@ DEV void post_place(const State &S, int lane, int K, unsigned env, bool leader, 
         S.order[S.Np + pos] = (int)env;
     }
 }
-template <int K>
-DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
+// FUSED (rem2d_rest_multi_kernel): instead of queueing a body that needs the TOI solve on the world's work list, return
+// true for its lane -- the caller solves it in this very wavefront.
+template <int K, bool FUSED>
+DEV bool post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
     const int lane = threadIdx.x;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
@@ -253,7 +255,7 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     const bool skipped = (misc & 0x200) != 0;
     if (__all(skipped ? 1 : 0)) {
         if (retile) post_place(S, lane, K, env, sub == 0, false);
-        return;
+        return false;
     }
 
     const int shape = LI(L_SHAPE);
@@ -355,7 +357,7 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     int envErr = group_or<K>(err);
     const float rootx = __shfl(px, base);
     if (retile) post_place(S, lane, K, env, sub == 0, envAwake && lastPosIters >= A.posIters && A.posIters > 2);
-    if (skipped) return; // (a creature pre left alone: nothing of it changes in this step)
+    if (skipped) return false; // (a creature pre left alone: nothing of it changes in this step)
     if (A.defer) { // continuous physics: the TOI kernel needs the sweep start and finishes the step
         const unsigned wb = (unsigned)SCR_SWEEP_BASE * Lp + gl;
         SW(wb, 0) = c0x; SW(wb, 1) = c0y; SW(wb, 2) = a0;
@@ -371,14 +373,30 @@ DEV void post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     if (!A.defer) env_bookkeeping(S, env, sub, rootx);
     // continuous physics: the TOI scan of this body, with its pose and sweep start still in registers (it was a kernel
     // of its own: one launch, one grid of early-exits and a round trip of the sweep start through HBM less per step)
-    else if (A.defer == 2) toi_scan_lane(S, T, A.dt, gl, env, sub, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
+    else if (A.defer == 2) {
+        if (!FUSED) {
+            toi_scan_lane(S, T, A.dt, gl, env, sub, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
+        } else {
+            const bool heavy = toi_scan_heavy(S, T, A.dt, gl, shape, px, py, ang, c0x, c0y, a0, hx, hy, awake, cCount);
+            if (!heavy && sub == 0) env_bookkeeping(S, env, 0, px);
+            return heavy;
+        }
+    }
+    return false;
+}
+template <int K> DEV void post_only_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
+    (void)post_body<K, false>(S, T, A, block, psh);
 }
 
 __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArgs A) {
     __shared__ PosShared psh;
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
-    BATCH_DISPATCH(post_body, psh)
+    BATCH_DISPATCH(post_only_body, psh)
 }
+
+// (Round 3 built "rest": post + the TOI solve of the wavefront's own bodies + the next step's pre in one launch, two
+// launches per step instead of four.  Bit-exact, but it needs the TOI solve's 256 VGPRs and was slower on every workload:
+// profiles/r03_fused_rest.txt.  Removed; post_body keeps the FUSED hook it used.)
 
 #endif
