@@ -151,9 +151,11 @@ def build_population(workload, n_envs, first):
     groups = {}
     for s in specs:
         groups.setdefault(lanes_for(s.n_bodies), []).append(s)
-    # creatures of one wave run in lockstep: sort every bucket by (pipeline period, joint rounds, bodies)
+    # creatures of one wave run in lockstep: sort every bucket by (pipeline period, joint rounds, bodies) -- the most
+    # complex first, so that their wavefronts (the long ones) are dispatched first
+    desc = os.environ.get("REM2D_SORT_DESC", "1") != "0"
     for k in groups:
-        groups[k].sort(key=lambda s: (s.period, max(s.rounds, default=-1), s.n_bodies))
+        groups[k].sort(key=lambda s: (s.period, max(s.rounds, default=-1), s.n_bodies), reverse=desc)
     morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
     if workload == "cppn_hardcore":
         return morphs, ("%d network-encoded creatures (synthetic feed-forward CPPN genome, seeds %d..%d), hardcore "

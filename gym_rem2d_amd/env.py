@@ -137,7 +137,9 @@ class BatchedModular2D:
         batches = []
         for lanes in sorted(groups):
             # creatures of one wave run in lockstep: keep waves homogeneous in joint rounds / size
-            idx = sorted(groups[lanes], key=lambda e: (specs[e].period, max(specs[e].rounds, default=-1), specs[e].n_bodies))
+            # (the most complex first: their wavefronts are the long ones and should be dispatched first)
+            idx = sorted(groups[lanes], key=lambda e: (specs[e].period, max(specs[e].rounds, default=-1), specs[e].n_bodies),
+                         reverse=os.environ.get("REM2D_SORT_DESC", "1") != "0")
             batches.append((Morphology.from_specs([specs[e] for e in idx], lanes), idx))
         self._upload(batches, len(specs))
 
