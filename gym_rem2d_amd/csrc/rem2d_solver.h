@@ -260,6 +260,113 @@ DEV void contact_solve(ContactC &c, float mB, float iB, float friction, float &v
     }
     vx = vB.x; vy = vB.y; w = wB;
 }
+// ---- the same solve by FOUR lanes (a quad: lanes 4k .. 4k+3, all of them active and holding the same constraint, body
+// constants and angular velocity).  One wavefront issues one instruction per ~6 cycles whatever the dependencies, so a
+// chain of solves costs its instruction COUNT; the lanes of a body's group are idle copies anyway (TOI kernel) -- here
+// they split the 2-vector arithmetic: lane q works on component (q & 1) (x / y) and, in the 2-point block solve, on point
+// (q >> 1).  Every scalar below is the serial form's expression on the same operands (a - b c == a + b (-c), the two
+// products of a dot / cross product added in either order: exact identities of IEEE arithmetic), so accumulated impulses
+// and velocities come out with the same bits.  v: this lane's velocity component; w, the impulses: the same in all four.
+struct QuadRole { float tq, nq, r0c, r1c; bool isY, pt1; };
+DEV float quad_swap1(float x) { // the value of lane ^ 1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)); // quad_perm [1,0,3,2]
+}
+DEV float quad_swap2(float x) { // the value of lane ^ 2
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
+}
+DEV QuadRole quad_role(const ContactC &c, int lane) {
+    QuadRole r;
+    r.isY = (lane & 1) != 0;
+    r.pt1 = (lane & 2) != 0;
+    r.nq = r.isY ? c.normal.y : c.normal.x;
+    r.tq = r.isY ? -c.normal.x : c.normal.y;   // tangent = cross(normal, 1) = (n.y, -n.x)
+    r.r0c = r.isY ? c.rB0.x : -c.rB0.y;        // cross(w, r) = (-w r.y, w r.x);  cross(r, P) = r.x P.y - r.y P.x
+    r.r1c = r.isY ? c.rB1.x : -c.rB1.y;
+    return r;
+}
+DEV void contact_solve_quad(ContactC &c, const QuadRole &r, float mB, float iB, float friction, float &v, float &w) {
+    {
+        float dv = v + w * r.r0c;
+        float p = dv * r.tq;
+        float vt = p + quad_swap1(p);
+        float lambda = c.tm0 * (-vt);
+        float maxFriction = friction * c.n0;
+        float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t0;
+        c.t0 = newImpulse;
+        float P = lambda * r.tq;
+        v = v + mB * P;
+        float cq = r.r0c * P;
+        w += iB * (cq + quad_swap1(cq));
+    }
+    if (c.count > 1) {
+        float dv = v + w * r.r1c;
+        float p = dv * r.tq;
+        float vt = p + quad_swap1(p);
+        float lambda = c.tm1 * (-vt);
+        float maxFriction = friction * c.n1;
+        float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t1;
+        c.t1 = newImpulse;
+        float P = lambda * r.tq;
+        v = v + mB * P;
+        float cq = r.r1c * P;
+        w += iB * (cq + quad_swap1(cq));
+    }
+    if (c.count == 1) {
+        float dv = v + w * r.r0c;
+        float p = dv * r.nq;
+        float vn = p + quad_swap1(p);
+        float lambda = -c.nm0 * vn;
+        float newImpulse = fmax32(c.n0 + lambda, 0.0f);
+        lambda = newImpulse - c.n0;
+        c.n0 = newImpulse;
+        float P = lambda * r.nq;
+        v = v + mB * P;
+        float cq = r.r0c * P;
+        w += iB * (cq + quad_swap1(cq));
+    } else {
+        V2 a = mk(c.n0, c.n1);
+        // lanes 0,1: point 0; lanes 2,3: point 1
+        float dv = v + w * (r.pt1 ? r.r1c : r.r0c);
+        float p = dv * r.nq;
+        float vnOwn = p + quad_swap1(p);
+        float vnOther = quad_swap2(vnOwn);
+        float vn1 = r.pt1 ? vnOther : vnOwn, vn2 = r.pt1 ? vnOwn : vnOther;
+        V2 b = mk(vn1, vn2);
+        b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
+        V2 x;
+        bool solved = false;
+        x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y)); // case 1
+        solved = x.x >= 0.0f && x.y >= 0.0f;
+        if (!solved) { // case 2
+            x.x = -c.nm0 * b.x;
+            x.y = 0.0f;
+            vn2 = c.k12 * x.x + b.y;
+            solved = x.x >= 0.0f && vn2 >= 0.0f;
+        }
+        if (!solved) { // case 3
+            x.x = 0.0f;
+            x.y = -c.nm1 * b.y;
+            vn1 = c.k12 * x.y + b.x;
+            solved = x.y >= 0.0f && vn1 >= 0.0f;
+        }
+        if (!solved) { // case 4
+            x.x = 0.0f;
+            x.y = 0.0f;
+            solved = b.x >= 0.0f && b.y >= 0.0f;
+        }
+        if (solved) {
+            V2 d = vsub(x, a);
+            float P1 = d.x * r.nq, P2 = d.y * r.nq;
+            v = v + mB * (P1 + P2);
+            float c1 = r.r0c * P1, c2 = r.r1c * P2;
+            w += iB * ((c1 + quad_swap1(c1)) + (c2 + quad_swap1(c2)));
+            c.n0 = x.x;
+            c.n1 = x.y;
+        }
+    }
+}
 // constraints beyond the register-resident ones live in handle scratch ([word][lane], coalesced)
 DEV void cc_store(const State &S, unsigned cb, const ContactC &c) {
     SW(cb, 0) = c.normal.x; SW(cb, 1) = c.normal.y; SW(cb, 2) = c.rB0.x; SW(cb, 3) = c.rB0.y;

@@ -695,10 +695,56 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                               mk(IW(t, 7), IW(t, 8)), mk(cx, cy), qn, mB, iB, radiusB, 0.0f, 0.0f, 0.0f, 0.0f);
                 cc_store(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
             }
+            if (G >= 4) {
+                // the lanes of this body's group are copies of each other: every quad of them splits the 2-vector arithmetic
+                // of a contact solve four ways (contact_solve_quad; same bits), this lane keeping component `lane & 1`
+                QuadRole role[KR];
+#pragma unroll
+                for (int t = 0; t < KR; ++t) role[t] = quad_role(tcc[t], lane);
+                const bool isY = (lane & 1) != 0;
+                float vq = isY ? B.vy : B.vx;
+                for (int it = 0; it < velIters; ++it) {
+                    // Exact early exit: one sweep is a deterministic function of (velocity, impulses); a sweep
+                    // that changes no bit is a fixed point, so every later sweep is the identity.  (Single-body
+                    // contact-only systems reach it after ~10 sweeps; the full 180 are never needed.)
+                    const unsigned hq = __float_as_uint(vq), h2 = __float_as_uint(B.w);
+                    bool changed = false;
+#pragma unroll
+                    for (int t = 0; t < KR; ++t) {
+                        if (t < nIsl) {
+                            const unsigned a0 = __float_as_uint(tcc[t].n0), a1 = __float_as_uint(tcc[t].n1);
+                            const unsigned a2 = __float_as_uint(tcc[t].t0), a3 = __float_as_uint(tcc[t].t1);
+                            contact_solve_quad(tcc[t], role[t], mB, iB, friction, vq, B.w);
+                            changed |= a0 != __float_as_uint(tcc[t].n0) || a1 != __float_as_uint(tcc[t].n1) ||
+                                       a2 != __float_as_uint(tcc[t].t0) || a3 != __float_as_uint(tcc[t].t1);
+                        }
+                    }
+                    if (nIsl > KR) { // (rare) further constraints go through scratch, solved by one lane's serial form
+                        float vo = quad_swap1(vq);
+                        float vx = isY ? vo : vq, vy = isY ? vq : vo;
+                        for (int t = KR; t < nIsl; ++t) {
+                            const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
+                            ContactC c;
+                            cc_load(S, cb, c);
+                            const unsigned a0 = __float_as_uint(c.n0), a1 = __float_as_uint(c.n1);
+                            const unsigned a2 = __float_as_uint(c.t0), a3 = __float_as_uint(c.t1);
+                            contact_solve(c, mB, iB, friction, vx, vy, B.w);
+                            changed |= a0 != __float_as_uint(c.n0) || a1 != __float_as_uint(c.n1) || a2 != __float_as_uint(c.t0) ||
+                                       a3 != __float_as_uint(c.t1);
+                            SW(cb, 10) = c.n0; SW(cb, 11) = c.n1; SW(cb, 12) = c.t0; SW(cb, 13) = c.t1;
+                        }
+                        vq = isY ? vy : vx;
+                    }
+                    int ch = (changed || hq != __float_as_uint(vq) || h2 != __float_as_uint(B.w)) ? 1 : 0;
+                    ch |= __builtin_amdgcn_update_dpp(0, ch, 0xB1, 0xf, 0xf, false); // the other component's lane
+                    if (!ch) break;
+                }
+                const float vo = quad_swap1(vq);
+                B.vx = isY ? vo : vq;
+                B.vy = isY ? vq : vo;
+            } else
             for (int it = 0; it < velIters; ++it) {
-                // Exact early exit: one sweep is a deterministic function of (velocity, impulses); a sweep
-                // that changes no bit is a fixed point, so every later sweep is the identity.  (Single-body
-                // contact-only systems reach it after ~10 sweeps; the full 180 are never needed.)
+                // (a group of fewer than four lanes per body -- the long work list after a reset: the serial form)
                 unsigned h0 = __float_as_uint(B.vx), h1 = __float_as_uint(B.vy), h2 = __float_as_uint(B.w);
                 bool changed = false;
 #pragma unroll
