@@ -260,7 +260,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
         w->tileShape = tile_shape_id();
         const TileShape shp = tile_shape(w->tileShape);
         // 4 sets = one phase per set: 128 / lanes creatures; fewer sets share phases, so keep to 64 joints in all
-        int per = (shp.sets >= V4_PHASES ? 128 : 64) / cfg->lanes;
+        int per = (shp.sets >= 4 ? 128 : 64) / cfg->lanes;
         if (per * cfg->lanes > shp.passes * WAVE) per = shp.passes * WAVE / cfg->lanes;
         if (per < 1) per = 1;
         std::vector<int32_t> ts;
@@ -305,7 +305,7 @@ extern "C" int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape_sel
     w->tileShape = tile_shape_sel;
     // the tile table in place may not fit the new shape: back to the default plan, valid for every morphology
     const TileShape shp = tile_shape(w->tileShape);
-    int per = (shp.sets >= V4_PHASES ? 128 : 64) / w->cfg.lanes;
+    int per = (shp.sets >= 4 ? 128 : 64) / w->cfg.lanes;
     if (per * w->cfg.lanes > shp.passes * WAVE) per = shp.passes * WAVE / w->cfg.lanes;
     if (per < 1) per = 1;
     std::vector<int32_t> ts;
@@ -687,16 +687,16 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     if (timed) {
         hipEvent_t e0 = w0->evPool[w0->evUsed].first, e1 = w0->evPool[w0->evUsed].second;
         switch (P.launchShape) {
-        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
         }
         w0->evUsed += 1;
     } else {
         switch (P.launchShape) {
-        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
         }
     }
     hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, P.B, P.A);

@@ -367,6 +367,88 @@ DEV void contact_solve_quad(ContactC &c, const QuadRole &r, float mB, float iB, 
         }
     }
 }
+// ---- the same solve by TWO lanes (a pair: lanes 2k, 2k + 1, both active, holding the same constraint; rem2d_vel4_kernel's
+// contact sub-slots).  Lane q works on component (q & 1) of the 2-vectors, both points of the block solve; the scalar
+// chain (impulse clamps, the 2 x 2 LCP) runs in both.  Same identities as contact_solve_quad: same bits.
+DEV void contact_solve_pair(ContactC &c, const QuadRole &r, float mB, float iB, float friction, float &v, float &w) {
+    {
+        float dv = v + w * r.r0c;
+        float p = dv * r.tq;
+        float vt = p + quad_swap1(p);
+        float lambda = c.tm0 * (-vt);
+        float maxFriction = friction * c.n0;
+        float newImpulse = fclamp(c.t0 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t0;
+        c.t0 = newImpulse;
+        float P = lambda * r.tq;
+        v = v + mB * P;
+        float cq = r.r0c * P;
+        w += iB * (cq + quad_swap1(cq));
+    }
+    if (c.count > 1) {
+        float dv = v + w * r.r1c;
+        float p = dv * r.tq;
+        float vt = p + quad_swap1(p);
+        float lambda = c.tm1 * (-vt);
+        float maxFriction = friction * c.n1;
+        float newImpulse = fclamp(c.t1 + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.t1;
+        c.t1 = newImpulse;
+        float P = lambda * r.tq;
+        v = v + mB * P;
+        float cq = r.r1c * P;
+        w += iB * (cq + quad_swap1(cq));
+    }
+    if (c.count == 1) {
+        float dv = v + w * r.r0c;
+        float p = dv * r.nq;
+        float vn = p + quad_swap1(p);
+        float lambda = -c.nm0 * vn;
+        float newImpulse = fmax32(c.n0 + lambda, 0.0f);
+        lambda = newImpulse - c.n0;
+        c.n0 = newImpulse;
+        float P = lambda * r.nq;
+        v = v + mB * P;
+        float cq = r.r0c * P;
+        w += iB * (cq + quad_swap1(cq));
+    } else {
+        V2 a = mk(c.n0, c.n1);
+        float p1 = (v + w * r.r0c) * r.nq, p2 = (v + w * r.r1c) * r.nq;
+        float vn1 = p1 + quad_swap1(p1), vn2 = p2 + quad_swap1(p2);
+        V2 b = mk(vn1, vn2);
+        b = vsub(b, mk(c.k11 * a.x + c.k12 * a.y, c.k12 * a.x + c.k22 * a.y));
+        V2 x;
+        bool solved = false;
+        x = vneg(mk(c.i11 * b.x + c.i12 * b.y, c.i12 * b.x + c.i22 * b.y)); // case 1
+        solved = x.x >= 0.0f && x.y >= 0.0f;
+        if (!solved) { // case 2
+            x.x = -c.nm0 * b.x;
+            x.y = 0.0f;
+            vn2 = c.k12 * x.x + b.y;
+            solved = x.x >= 0.0f && vn2 >= 0.0f;
+        }
+        if (!solved) { // case 3
+            x.x = 0.0f;
+            x.y = -c.nm1 * b.y;
+            vn1 = c.k12 * x.y + b.x;
+            solved = x.y >= 0.0f && vn1 >= 0.0f;
+        }
+        if (!solved) { // case 4
+            x.x = 0.0f;
+            x.y = 0.0f;
+            solved = b.x >= 0.0f && b.y >= 0.0f;
+        }
+        if (solved) {
+            V2 d = vsub(x, a);
+            float P1 = d.x * r.nq, P2 = d.y * r.nq;
+            v = v + mB * (P1 + P2);
+            float c1 = r.r0c * P1, c2 = r.r1c * P2;
+            w += iB * ((c1 + quad_swap1(c1)) + (c2 + quad_swap1(c2)));
+            c.n0 = x.x;
+            c.n1 = x.y;
+        }
+    }
+}
 // constraints beyond the register-resident ones live in handle scratch ([word][lane], coalesced)
 DEV void cc_store(const State &S, unsigned cb, const ContactC &c) {
     SW(cb, 0) = c.normal.x; SW(cb, 1) = c.normal.y; SW(cb, 2) = c.rB0.x; SW(cb, 3) = c.rB0.y;

@@ -31,7 +31,7 @@
 //   WPS     waves per SIMD the register allocation targets.
 // More bodies per tile = fewer wavefronts and fuller joint slots; fewer registers = more resident wavefronts to hide
 // the dependent-instruction latency (~10 cycles per instruction for a lone wavefront, measured with s_memtime).
-#define V4_PHASES 4        // largest schedule period supported (reference modules: <= 4)
+#define V4_PHASES 5        // largest schedule period the tick loop is unrolled for (reference modules need <= 4; a tile may take one more)
 #define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
 #define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
@@ -179,6 +179,7 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
 // one contact lane: the manifold's constraint, its body's inverse mass and its place in the schedule
 struct ContactT {
     ContactC c;
+    QuadRole r; // CPAIR: this lane's component of the pair solve (rem2d_solver.h)
     float mB;
     int key; // body | sub-slot << 8 | manifold index << 12 | first tick << 16 | (first tick mod P) << 24 | valid << 31
 };
@@ -190,9 +191,9 @@ static_assert(KT <= 16, "manifold index: 4 bits");
 #define V4_CPHASE(k) (((k) >> 24) & 0x7)
 
 // the contact sub-slots of the tick `tick` (phase ph): every manifold scheduled here, in the order of its body's list
-template <int CSETS, typename SH>
+template <int CSETS, bool CPAIR, typename SH>
 DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsigned tb0, int lane, int NC, bool spill,
-                             int nsub, int ph, int tick, int span, float mu) {
+                             bool pair, int nsub, int ph, int tick, int span, float mu) {
     const unsigned Lp = S.Lp;
     for (int t = 0; t < nsub; ++t) {
 #pragma unroll
@@ -202,12 +203,19 @@ DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsig
                 (unsigned)(tick - V4_COFF(C[cs].key)) < (unsigned)span) {
                 const int b = V4_CBODY(C[cs].key);
                 V4Vel v = sh.vel[b];
-                contact_solve(C[cs].c, C[cs].mB, v.invI, mu, v.x, v.y, v.w);
-                sh.vel[b] = v;
+                if (!CPAIR || !pair) {
+                    contact_solve(C[cs].c, C[cs].mB, v.invI, mu, v.x, v.y, v.w);
+                    sh.vel[b] = v;
+                } else { // two lanes per manifold: this one carries component (lane & 1) of the body's velocity
+                    float vq = C[cs].r.isY ? v.y : v.x;
+                    contact_solve_pair(C[cs].c, C[cs].r, C[cs].mB, v.invI, mu, vq, v.w);
+                    if (!C[cs].r.isY) sh.vel[b].x = vq;
+                    else { sh.vel[b].y = vq; sh.vel[b].w = v.w; }
+                }
             }
         }
         if (spill) {
-            for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+            for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) { // (a tile that spills is not in pair mode)
                 const int e = (int)sh.cmap[ci];
                 const int b = V4_CBODY(e);
                 if (V4_CSUB(e) != t || V4_CPHASE(e) != ph || !((unsigned)(tick - V4_COFF(e)) < (unsigned)span)) continue;
@@ -225,7 +233,7 @@ DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsig
     }
 }
 
-template <int SETS, int PASSES, int CSETS>
+template <int SETS, int PASSES, int CSETS, bool CPAIR>
 DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsigned tile, int K, Vel4Shared<SETS, PASSES> &sh) {
     const int lane = threadIdx.x;
     const unsigned Lp = S.Lp;
@@ -291,58 +299,92 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     // (2) creatures are independent, so each one may run its whole schedule -- joint rounds and contact ticks alike --
     //     any number of ticks late: every creature is rotated so that its heaviest contact phase (the most manifolds on
     //     one body) falls on phase 0 of the tile.  Only with one joint register set: the host packed the others by phase.
+    // (3) the period itself is a choice: the schedule is valid for any period >= the creatures' own (compiler.pipeline_schedule),
+    //     and one more tick per iteration widens every body's window by one, so that bodies whose windows did not meet can
+    //     share a contact tick.  A tile whose contact sub-slots outweigh a joint slot takes the longer period: the slowest
+    //     tiles of a launch are such tiles (period 3-4 with 5-6 sub-slots per iteration, profiles/r03_slow_tiles.txt).
+    //     Again only with one joint register set.
     const unsigned long long groupLanes = (K >= WAVE ? ~0ull : ((1ull << K) - 1ull)) << (lane & ~(K - 1) & (WAVE - 1));
-    int wlo[PASSES], wlen[PASSES], offB[PASSES], delta[PASSES];
-    bool placed[PASSES];
+    int offB[PASSES], delta[PASSES];
+    // the plan for period Pc: every body's contact tick offB (iteration 0) and its creature's rotation delta; returns the
+    // contact sub-slots per iteration of the whole tile under that plan
+    auto plan = [&](const int Pc) -> int {
+        int wlo[PASSES], wlen[PASSES];
+        bool placed[PASSES];
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int bl = p * WAVE + lane;
-        const bool solve = (misc[p] & 0x100) != 0;
-        const int nT = solve ? (misc[p] & 0xff) : 0;
-        const int lastB = sh.lastR[bl];
-        wlo[p] = lastB >= 0 ? lastB : 0;                          // first tick of the window (iteration 0)
-        wlen[p] = lastB >= 0 ? sh.firstR[bl] + P - lastB : P;     // its length in ticks, 1 .. P
-        offB[p] = wlo[p];
-        placed[p] = nT == 0;
-        delta[p] = 0;
-    }
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int wl = wlo[p] % P;
-        for (int round = 0; round < P && round < V4_PHASES; ++round) { // per creature (the lanes of groupLanes)
-            int cover[V4_PHASES];
-#pragma unroll
-            for (int s = 0; s < V4_PHASES; ++s) {
-                int d = s - wl;
-                d = d < 0 ? d + P : d;
-                cover[s] = __popcll(__ballot(!placed[p] && s < P && d < wlen[p]) & groupLanes);
-            }
-            int cstar = 0;
-#pragma unroll
-            for (int s = 1; s < V4_PHASES; ++s) cstar = (s < P && cover[s] >= cover[cstar]) ? s : cstar;
-            int dstar = cstar - wl;
-            dstar = dstar < 0 ? dstar + P : dstar;
-            if (!placed[p] && cover[cstar] > 0 && dstar < wlen[p]) {
-                offB[p] = wlo[p] + dstar;
-                placed[p] = true;
-            }
-        }
-        if (SETS == 1) {
+        for (int p = 0; p < PASSES; ++p) {
+            const int bl = p * WAVE + lane;
             const bool solve = (misc[p] & 0x100) != 0;
             const int nT = solve ? (misc[p] & 0xff) : 0;
-            const int cph = offB[p] % P;
-            int heavyPhase = 0, heavy = 0; // the creature's phase with the most manifolds on one body (ties: the first)
+            const int lastB = sh.lastR[bl];
+            wlo[p] = lastB >= 0 ? lastB : 0;                          // first tick of the window (iteration 0)
+            wlen[p] = lastB >= 0 ? sh.firstR[bl] + Pc - lastB : Pc;   // its length in ticks, 1 .. Pc
+            offB[p] = wlo[p];
+            placed[p] = nT == 0;
+            delta[p] = 0;
+        }
+        int subs[V4_PHASES];
+#pragma unroll
+        for (int s = 0; s < V4_PHASES; ++s) subs[s] = 0;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int wl = wlo[p] % Pc;
+            for (int round = 0; round < Pc && round < V4_PHASES; ++round) { // per creature (the lanes of groupLanes)
+                int cover[V4_PHASES];
+#pragma unroll
+                for (int s = 0; s < V4_PHASES; ++s) {
+                    int d = s - wl;
+                    d = d < 0 ? d + Pc : d;
+                    cover[s] = __popcll(__ballot(!placed[p] && s < Pc && d < wlen[p]) & groupLanes);
+                }
+                int cstar = 0;
+#pragma unroll
+                for (int s = 1; s < V4_PHASES; ++s) cstar = (s < Pc && cover[s] >= cover[cstar]) ? s : cstar;
+                int dstar = cstar - wl;
+                dstar = dstar < 0 ? dstar + Pc : dstar;
+                if (!placed[p] && cover[cstar] > 0 && dstar < wlen[p]) {
+                    offB[p] = wlo[p] + dstar;
+                    placed[p] = true;
+                }
+            }
+            const bool solve = (misc[p] & 0x100) != 0;
+            const int nT = solve ? (misc[p] & 0xff) : 0;
+            if (SETS == 1) {
+                const int cph = offB[p] % Pc;
+                int heavyPhase = 0, heavy = 0; // the creature's phase with the most manifolds on one body (ties: the first)
+#pragma unroll
+                for (int s = 0; s < V4_PHASES; ++s) {
+                    int most = 0;
+#pragma unroll
+                    for (int n = 1; n <= KT; ++n) most = (__ballot(nT >= n && cph == s) & groupLanes) ? n : most;
+                    if (s < Pc && most > heavy) { heavy = most; heavyPhase = s; }
+                }
+                delta[p] = heavy > 0 ? (Pc - heavyPhase) % Pc : 0;
+            }
+            const int cphr = (offB[p] + delta[p]) % Pc;
 #pragma unroll
             for (int s = 0; s < V4_PHASES; ++s) {
-                int most = 0;
 #pragma unroll
-                for (int n = 1; n <= KT; ++n) most = (__ballot(nT >= n && cph == s) & groupLanes) ? n : most;
-                if (s < P && most > heavy) { heavy = most; heavyPhase = s; }
+                for (int n = 1; n <= KT; ++n)
+                    if (__ballot(nT >= n && cphr == s)) subs[s] = max(subs[s], n);
             }
-            delta[p] = heavy > 0 ? (P - heavyPhase) % P : 0;
         }
-        sh.firstR[p * WAVE + lane] = delta[p]; // (the windows are done with: the joint role reads its creature's rotation here)
+        int total = 0;
+#pragma unroll
+        for (int s = 0; s < V4_PHASES; ++s) total += subs[s];
+        return total;
+    };
+    {
+        const int subsP = plan(P);
+        // a joint slot costs ~0.7 of a contact sub-slot (profiles/r03_slow_tiles.txt: 850-1000 vs 1150-1400 cycles)
+        if (SETS == 1 && P < V4_PHASES && subsP >= 2) {
+            const int subsQ = plan(P + 1);
+            if (7 * (P + 1) + 10 * subsQ < 7 * P + 10 * subsP) P = P + 1;
+            else (void)plan(P); // (back to the plan for P)
+        }
     }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) sh.firstR[p * WAVE + lane] = delta[p]; // (the windows are done with: the joint role reads its creature's rotation here)
     lds_sync();
 
     int NC = 0, lastTick = -1, maxRound = -1, err = 0, maxT = 0;
@@ -407,12 +449,19 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     }
     // ---------------- contact role: manifold `lane + 64 cs` of the tile; beyond CSETS * 64 through scratch ----------------
     ContactT C[CSETS];
+    const bool pair = CPAIR && NC <= CSETS * (WAVE / 2); // wave-uniform
 #pragma unroll
     for (int cs = 0; cs < CSETS; ++cs) {
         C[cs].key = 0;
         C[cs].c.count = 0;
         C[cs].mB = 0.0f;
-        const int ci = cs * WAVE + lane;
+        C[cs].r.tq = C[cs].r.nq = C[cs].r.r0c = C[cs].r.r1c = 0.0f;
+        C[cs].r.isY = (lane & 1) != 0;
+        C[cs].r.pt1 = false;
+        // pair mode (CPAIR, and the tile's manifolds fit half the lanes -- a 64-body tile of 8- or 16-lane creatures has ~15):
+        // manifold ci on the lane pair 2 ci, 2 ci + 1 of its register set, both lanes with the whole constraint and one
+        // component each of the arithmetic (contact_solve_pair)
+        const int ci = pair ? cs * (WAVE / 2) + (lane >> 1) : cs * WAVE + lane;
         if (ci < NC) {
             const int e = (int)sh.cmap[ci];
             const int b = V4_CBODY(e), t = V4_CT(e);
@@ -420,9 +469,11 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             C[cs].key = e | (int)0x80000000;
             C[cs].mB = LF(L_INVM);
             cc_load(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, C[cs].c);
+            C[cs].r = quad_role(C[cs].c, lane);
         }
     }
-    const bool spill = NC > CSETS * WAVE; // wave-uniform
+    const int CCAP = CSETS * WAVE; // manifolds in registers (classic mode; a tile in pair mode has at most half as many)
+    const bool spill = NC > CCAP; // wave-uniform
     // ---------------- warm start: contacts (per body in list order), then joints in island rounds ----------------
     for (int t = 0; t < maxT; ++t) {
 #pragma unroll
@@ -435,7 +486,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             }
         }
         if (spill) {
-            for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+            for (int ci = CCAP + lane; ci < NC; ci += WAVE) {
                 const int e = (int)sh.cmap[ci];
                 const int b = V4_CBODY(e);
                 if (V4_CT(e) != t) continue;
@@ -490,7 +541,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                         (unsigned)(tick - V4_JROUND(Js.key)) < (unsigned)span) v4_joint_slot(Js, sh);
                     lds_sync();
                     if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tJ += t1 - t0; }
-                    v4_contact_subslots(S, C, sh, tb0, lane, NC, spill, subMax[s], s, tick, span, mu);
+                    v4_contact_subslots<CSETS, CPAIR>(S, C, sh, tb0, lane, NC, spill, pair, subMax[s], s, tick, span, mu);
                     if (stamp) { tC += __builtin_amdgcn_s_memtime() - t1; nSub += subMax[s]; }
                 }
             }
@@ -517,7 +568,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     // ---------------- StoreImpulses, joint impulses, body velocities ----------------
 #pragma unroll
     for (int cs = 0; cs < CSETS; ++cs) {
-        if (V4_VALID(C[cs].key)) {
+        if (V4_VALID(C[cs].key) && !(pair && (lane & 1))) { // (one lane of a pair stores)
             const int b = V4_CBODY(C[cs].key), t = V4_CT(C[cs].key);
             const unsigned gl = tb0 + (unsigned)b;
             const slotpack_t sp = sp_load(S, (unsigned)SCR_MISC_BASE * Lp + gl);
@@ -531,7 +582,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
     if (spill) {
-        for (int ci = CSETS * WAVE + lane; ci < NC; ci += WAVE) {
+        for (int ci = CCAP + lane; ci < NC; ci += WAVE) {
             const int e = (int)sh.cmap[ci];
             const int b = V4_CBODY(e), t = V4_CT(e);
             const unsigned gl = tb0 + (unsigned)b;
@@ -582,14 +633,14 @@ struct Vel4Batch {
     int lanes[REM2D_MAX_BATCH];
     int n;
 };
-template <int SETS, int PASSES, int CSETS, int WPS>
+template <int SETS, int PASSES, int CSETS, int WPS, bool CPAIR>
 __global__ __launch_bounds__(WAVE, WPS) void rem2d_vel4_kernel(Vel4Batch B, Vel4Args A) {
     __shared__ Vel4Shared<SETS, PASSES> sh;
     unsigned tile = blockIdx.x;
     int b = 0;
     while (b + 1 < B.n && tile >= B.tileEnd[b]) ++b;
     if (b > 0) tile -= B.tileEnd[b - 1];
-    vel4_body<SETS, PASSES, CSETS>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
+    vel4_body<SETS, PASSES, CSETS, CPAIR>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
 }
 
 #endif
