@@ -431,8 +431,12 @@ class Modular2D(gymshim.Env):
         # between resets, so count once
         self._n_ctrl = sum(1 for n in self.tree_morphology.nodes
                            if n.controller is not None and n.expressed and n.component is not None)
-        import torch
-        self._out = torch.empty(2, dtype=torch.float32, device=self.world.device)
+        # reward / done of every step land in pinned, device-mapped host memory, written by the step's own kernels
+        # (rem2d_world_set_outputs): step() needs no copy kernel and no device -> host memcpy, only the stream's completion
+        self._pin_reward = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._pin_done = torch.zeros(1, dtype=torch.bool).pin_memory()
+        self._pin_index = torch.zeros(1, dtype=torch.int32, device=self.world.device)
+        self.world.set_outputs(self._pin_reward, self._pin_done, self._pin_index)
         return
 
     def step(self, action):
@@ -442,10 +446,8 @@ class Modular2D(gymshim.Env):
             raise Exception("no tree_morphology")
         assert self._n_ctrl - 1 == len(self.robot.joints)
         self.world.step(1)                      # one creature: straight to the C ABI, no bucket / group bookkeeping
-        self._out[0] = self.world.view("reward")[0]
-        self._out[1] = self.world.view("done")[0]
-        r, d = self._out.tolist()               # one device -> host copy per step (the caller wants python scalars)
-        d = d != 0.0
+        torch.cuda.current_stream(self.world.device).synchronize()
+        r, d = float(self._pin_reward[0]), bool(self._pin_done[0])   # (host reads of the mapped buffer the kernels wrote)
         return 0, (r if not d else -100), (True if d else 0), 0
 
     def render(self, mode='human'):
