@@ -61,7 +61,7 @@ def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950; newest round first)."""
-    for name in ("r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_f_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_f_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -92,19 +92,25 @@ def pmc_traffic_all():
 
 def valu_issue(n_groups):
     """VALU wave-instructions per env-step of the default population from the committed SQ-counter pass
-    (profiles/r02_b_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
-    measured issue peak (tools/ubench_latency.hip -> profiles/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s)."""
-    path = os.path.join(ROOT, "profiles", "r02_b_sq_counters.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except Exception:  # noqa: BLE001
-        return None
-    per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
-                    if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi")))
-    return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
-            "source": "profiles/r02_b_sq_counters.json (per launch of one of the %d step groups of this command), "
-                      "profiles/r02_b_ubench_valu_latency.txt" % n_groups}
+    (profiles/r03_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
+    measured issue peak (tools/ubench_latency.hip -> profiles/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s
+    with 8 dependent chains per SIMD).  Only when this run uses the step-group count the counters were collected with."""
+    for name in ("r03_sq_counters.json", "r02_b_sq_counters.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:  # noqa: BLE001
+            continue
+        groups = d.get("step_groups") or 4      # (the round-2 file predates the field: four groups)
+        if groups != n_groups:
+            return None
+        per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
+                        if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi")))
+        return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
+                "source": "profiles/%s (per launch of one of the %d step groups of this command), "
+                          "profiles/r02_b_ubench_valu_latency.txt" % (name, n_groups)}
+    return None
 
 
 def build_population(workload, n_envs, first):

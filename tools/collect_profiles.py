@@ -87,6 +87,7 @@ def main():
                    "--kernel-trace --output-format csv -- " + args[3],
                    "note": "means over the last %d launches of each kernel; active_lanes_per_valu_inst = SQ_THREAD_CYCLES_VALU / "
                            "SQ_INSTS_VALU (64 = every lane active)" % tail,
+                   "step_groups": int(args[4]) if len(args) > 4 else None,
                    "kernels": c}, open(args[2], "w"), indent=1)
     elif mode == "trace":
         n = int(args[3])

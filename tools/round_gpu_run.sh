@@ -1,22 +1,26 @@
 #!/bin/bash
-# Everything measured for a round, on the GPU box: gpurun --timeout 1500 -- 'bash tools/round_gpu_run.sh'
-# (each command under its own timeout so that a hang cannot eat the GPU budget)
+# Everything measured for a round, on the GPU box: gpurun --timeout 2400 -- 'bash tools/round_gpu_run.sh r03_final'
+# (each command under its own timeout so that a hang cannot eat the GPU budget).  The driver's command runs FIRST, as the
+# first GPU process of the lease (cold), then again (warm).
 set -u
-O=gpurun_out/r02_final; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_default_20.json 2>/dev/null
-timeout 300 python bench.py --steps 200 --warmup 20 > $O/bench_default.json 2>/dev/null
-timeout 300 python bench.py --workload chain8 --no-cpu-baseline > $O/bench_chain8.json 2>/dev/null
-timeout 300 python bench.py --workload chain4 --no-cpu-baseline > $O/bench_chain4.json 2>/dev/null
-timeout 300 python bench.py --workload cppn_hardcore --no-cpu-baseline > $O/bench_cppn.json 2>/dev/null
-timeout 300 python bench.py --workload generation --no-cpu-baseline > $O/bench_generation.json 2>/dev/null
-timeout 300 python bench.py --workload single --steps 1000 --warmup 0 > $O/bench_single.json 2>/dev/null
-timeout 300 python bench.py --discrete --no-cpu-baseline > $O/bench_discrete.json 2>/dev/null
-timeout 300 python bench.py --pipeline 0 --no-cpu-baseline > $O/bench_fused.json 2>/dev/null
-timeout 300 python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_2ranks_1gpu.json 2>/dev/null
-for f in $O/bench_*.json; do python -c "
-import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], '%.2fM'%(d['value']/1e6), '%.3f ms/step'%d['ms_per_step'], 'err', d['config']['solver_errors'])"; done
-bash tools/profile_round.sh r02_b > $O/profile.log 2>&1; tail -3 $O/profile.log
-REM2D_TILE_SHAPE=0 timeout 420 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $O/sq0 -- python3 bench.py --steps 10 --warmup 2 --settle 80 --no-cpu-baseline > /dev/null 2> $O/sq0.err
-python3 tools/collect_profiles.py sq $O/sq0 $O/r02_b_sq_counters_tile_shape0.json "REM2D_TILE_SHAPE=0 python3 bench.py --steps 10 --warmup 2 --settle 80 --no-cpu-baseline"; rm -rf $O/sq0
-timeout 600 python tools/soak_parity.py --n 6000 --steps 300 > $O/soak_parity.txt 2>&1; tail -5 $O/soak_parity.txt
+TAG=${1:-r03_final}
+O=gpurun_out/$TAG; mkdir -p $O
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20_cold.json 2> $O/bench_cold.err
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20.json 2>/dev/null
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 600 python3 bench.py --steps 200 --warmup 20 --no-secondary > $O/bench_default.json 2>/dev/null
+timeout 300 python3 bench.py --workload chain8 --no-cpu-baseline > $O/bench_chain8.json 2>/dev/null
+timeout 300 python3 bench.py --workload chain4 --no-cpu-baseline > $O/bench_chain4.json 2>/dev/null
+timeout 300 python3 bench.py --workload cppn_hardcore --no-cpu-baseline > $O/bench_cppn.json 2>/dev/null
+timeout 300 python3 bench.py --workload generation --no-cpu-baseline > $O/bench_generation.json 2>/dev/null
+timeout 300 python3 bench.py --workload single --steps 1000 --warmup 0 --min-time 0 > $O/bench_single.json 2>/dev/null
+timeout 300 python3 bench.py --discrete --no-cpu-baseline --no-secondary > $O/bench_discrete.json 2>/dev/null
+timeout 300 python3 bench.py --pipeline 0 --no-cpu-baseline --no-secondary > $O/bench_fused.json 2>/dev/null
+timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_2ranks_1gpu_weak.json 2>/dev/null
+timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --scaling strong > $O/bench_2ranks_1gpu_strong.json 2>/dev/null
+timeout 120 python3 tools/bench_facade.py 2000 > $O/facade.txt 2>/dev/null
+for f in $O/bench_*.json; do python3 -c "
+import json,sys; d=json.load(open('$f')); c=d['config']; print('$f'.split('/')[-1], '%.2fM'%(d['value']/1e6), '%.3f ms/step'%d['ms_per_step'], 'blocks', c['blocks'], 'first %.1f med %.1f ms' % (c['block_ms_first'], c['block_ms_median']), 'err', c['solver_errors'], {k: round(v['value']/1e6,1) for k,v in (d.get('secondary') or {}).items()})"; done
+cat $O/facade.txt
+bash tools/profile_round.sh ${TAG%_final} > $O/profile.log 2>&1; tail -3 $O/profile.log
+timeout 600 python tools/soak_parity.py --n 6000 --steps 300 > $O/soak_parity.txt 2>&1; tail -4 $O/soak_parity.txt
