@@ -104,6 +104,46 @@ def test_merged_launch_equals_per_bucket_streams(need_gpu):
     assert np.array_equal(f0, f1)
 
 
+def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
+    """rem2d_groups_step: the whole population's step groups in ONE ABI call (fork from the caller's stream, the steps of
+    the groups queued round-robin, join), plain and replayed as a hipGraph (REM2D_STEP_GRAPH: captured on the first call
+    of a given length, re-captured when a world's tiles change).  Fitness and steps equal the oracle's in every bit for
+    one, three and four groups; an ABI misuse is refused."""
+    import ctypes as C
+    import torch
+    from conftest import oracle_terrain
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology, lanes_for
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(160), mutate_odd=True)
+    ot = oracle_terrain(oracle, rough_terrain)
+    ref = np.zeros(len(specs))
+    groups = {}
+    for e, sp in enumerate(specs):
+        groups.setdefault(lanes_for(sp.n_bodies), []).append(e)
+    T = 150
+    for k in sorted(groups):
+        m = Morphology.from_specs([specs[e] for e in groups[k]], k)
+        ref[groups[k]] = oracle.batch_run(ot, m.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)["fitness"]
+    for n_groups, graph in ((1, False), (3, False), (4, False), (4, True), (3, True)):
+        env = BatchedModular2D(seed=4, flags=_lib.FLAG_CONTINUOUS)
+        env.step_groups = n_groups
+        env.use_graph = graph
+        env.reset_specs(specs)
+        assert len(env.groups) == n_groups
+        for n in (1, 24, 25, 25, 25, 25, 25):      # (25 five times: the graph of that length is captured once, replayed four times)
+            env.step(n)
+        torch.cuda.synchronize()
+        assert np.array_equal(env.fitness.cpu().numpy(), ref), (n_groups, graph)
+        assert bool((env.steps == T).all()) and int(env.errors().max()) == 0
+        env.close()
+    L = _lib.lib()
+    g = (_lib.StepGroup * 1)()
+    g[0].worlds, g[0].n_worlds, g[0].stream = None, 0, None
+    assert L.rem2d_groups_step(g, 1, 1, None, 0) == -1 and b"no worlds" in L.rem2d_last_error()
+    assert L.rem2d_groups_step(g, _lib.MAX_STEP_GROUPS + 1, 1, None, 0) == -1
+
+
 def test_array_population_fitness_is_order_independent(need_gpu):
     """population.LSystemPopulation -> native compiler -> batched episodes: the fitness of an individual does not
     depend on where it sits in the population (bucket sorting / step groups / index gathering are transparent)."""
