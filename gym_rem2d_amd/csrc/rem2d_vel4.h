@@ -376,10 +376,13 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     };
     {
         const int subsP = plan(P);
-        // a joint slot costs ~0.7 of a contact sub-slot (profiles/r03_slow_tiles.txt: 850-1000 vs 1150-1400 cycles)
-        if (SETS == 1 && P < V4_PHASES && subsP >= 2) {
+        // a joint slot costs ~0.7 of a HEAVY contact sub-slot (profiles/r03_slow_tiles.txt: 850-1000 vs 1150-1400 cycles) but
+        // about as much as a light one (800): only a gain of two sub-slots is worth a tick.  (Longer periods still -- up to
+        // the creatures' round count, where every window contains one common tick -- need the tick loop rolled instead of
+        // unrolled per phase; measured: the rolled loop costs 4 % per tick, more than the few tiles it helps gain.)
+        if (SETS == 1 && P < V4_PHASES && subsP >= 3) {
             const int subsQ = plan(P + 1);
-            if (7 * (P + 1) + 10 * subsQ < 7 * P + 10 * subsP) P = P + 1;
+            if (subsQ + 2 <= subsP) P = P + 1;
             else (void)plan(P); // (back to the plan for P)
         }
     }
