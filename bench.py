@@ -473,11 +473,11 @@ def main():
     timing_steps = 0
     if not generation:
         firsts = [env.worlds[g[0]][0] for g in env.groups] if env.groups else [env.worlds[0][0]]
-        for w in firsts:          # event pairs are created here; only each group's first world records
-            w.enable_timing(True)
+        timing_steps = min(args.steps, 200)
+        for w in firsts:          # event pairs are created here (as many as this pass records); only each group's first world records
+            w.enable_timing(timing_steps + 8)
             w.kernel_time_ms()
             w.step_time_ms()
-        timing_steps = min(args.steps, 200)
         sync()
         run(timing_steps)
         sync()

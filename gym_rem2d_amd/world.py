@@ -155,7 +155,9 @@ class BatchedWorld:
         return torch.stack(cols, dim=-1).cpu().numpy()
 
     def enable_timing(self, on=True):
-        self._check(self.L.rem2d_world_enable_timing(self.h, 1 if on else 0))
+        """on: False / 0 = off; True = on with room for 4096 timed launches between two read-backs; an int > 1 = on with
+        room for that many (the event pairs are created here, two pools of that size)."""
+        self._check(self.L.rem2d_world_enable_timing(self.h, int(on) if on is not True else 1))
 
     def step_time_ms(self):
         """(device ms, steps) of the whole kernel sequence of the env-steps since the last call (tile pipeline)."""
