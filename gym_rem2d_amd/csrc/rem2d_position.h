@@ -252,30 +252,32 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         POS_STAMP(pJ)
         // ---- verdict on the iteration whose last joint has just run (creature-uniform) ----
         const bool due = tick == nextD;
-        // (one ballot and the creature's lane mask instead of a K-lane shuffle reduction in every tick)
-        const unsigned long long failedLanes = __ballot(due && ((failBits >> (itD & 63)) & 1ull) != 0ull);
-        const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
-        const bool failed = (failedLanes & groupLanes) != 0ull;
-        if (due) failBits &= ~(1ull << (itD & 63)); // the mask is a ring: at most POS_RING iterations are in flight
-        bool restored = false;
-        if (due) {
-            if (!failed) { // Box2D breaks here: drop whatever later iterations have already done
-                envSolved = true;
-                itersUsed = itD + 1;
-                nextC = nextJ = nextD = 0x7fffffff;
-                if (hasOps) {
-                    const int r = itD & (POS_RING - 1);
-                    sh.pos[lane] = sh.snap[r][lane];
-                    restored = true;
+        if (__any(due ? 1 : 0)) { // (a wavefront whose only unfinished creature has period P is due once in P ticks)
+            // (one ballot and the creature's lane mask instead of a K-lane shuffle reduction in every tick)
+            const unsigned long long failedLanes = __ballot(due && ((failBits >> (itD & 63)) & 1ull) != 0ull);
+            const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
+            const bool failed = (failedLanes & groupLanes) != 0ull;
+            if (due) failBits &= ~(1ull << (itD & 63)); // the mask is a ring: at most POS_RING iterations are in flight
+            bool restored = false;
+            if (due) {
+                if (!failed) { // Box2D breaks here: drop whatever later iterations have already done
+                    envSolved = true;
+                    itersUsed = itD + 1;
+                    nextC = nextJ = nextD = 0x7fffffff;
+                    if (hasOps) {
+                        const int r = itD & (POS_RING - 1);
+                        sh.pos[lane] = sh.snap[r][lane];
+                        restored = true;
+                    }
+                } else {
+                    ++itD;
+                    nextD = itD < posIters ? nextD + P : 0x7fffffff;
                 }
-            } else {
-                ++itD;
-                nextD = itD < posIters ? nextD + P : 0x7fffffff;
             }
+            if (__any(restored ? 1 : 0)) lds_sync();
+            if (__all(nextD == 0x7fffffff ? 1 : 0)) break;
         }
-        if (__any(restored ? 1 : 0)) lds_sync();
         POS_STAMP(pV)
-        if (__all(nextD == 0x7fffffff ? 1 : 0)) break;
     }
 #ifdef REM2D_POS_STAMPS
     if (lane == 0 && pTicks >= 40 * P) { // the wavefronts that iterate to the end only
