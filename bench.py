@@ -245,6 +245,8 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
     want = int(budget_s * est_rate / (settle + window))
     sample = sample_of(min(total, max(256, 48 * cores, min(want, 8192))))
     n = sample["n_envs"]
+    # (the sample is capped: a longer window of the same creatures fills the budget instead -- about 10-20 s of CPU work)
+    window = int(max(window, min(budget_s * est_rate / n - settle, 800)))
     tw, _ = O.batch_window(ot, sample, settle, window, n_threads=cores, flags=flags)
     all_threads = n * window / max(tw, 1e-6)
     return {"value": all_threads, "unit": "env-steps/s", "cores": cores, "kind": "port", "is_oracle": True,
