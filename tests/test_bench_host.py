@@ -62,3 +62,27 @@ def test_cpu_baseline_times_the_gpu_legs_window(oracle):
     a = oracle.batch_run(ot, m.as_dict(), 40, n_threads=2, flags=1)["bodies"]
     b = oracle.batch_run(ot, bench._repack(m, 16), 40, n_threads=2, flags=1)["bodies"]
     assert np.array_equal(a, b[:, :m.lanes]) and not b[:, m.lanes:].any()
+
+
+def test_timed_blocks_protocol():
+    """Blocks of exactly K steps between a sync on both sides, repeated until the timed region reaches min_time (at least
+    one block, at most max_blocks); the block time every rank sees is the reduced (max over ranks) one."""
+    import bench
+    calls = {"sync": 0, "steps": []}
+    clock = iter(range(1000))
+
+    def fake_block(n):
+        calls["steps"].append(n)
+
+    def sync():
+        calls["sync"] += 1
+    blocks = bench.timed_blocks(fake_block, 20, 0.0, 10, sync, lambda x: 0.25)
+    assert blocks == [0.25] and calls["steps"] == [20] and calls["sync"] == 2
+    calls.update(sync=0, steps=[])
+    blocks = bench.timed_blocks(fake_block, 7, 1.0, 100, sync, lambda x: 0.3)
+    assert blocks == [0.3] * 4 and calls["steps"] == [7] * 4 and calls["sync"] == 8     # 4 x 0.3 s >= 1 s
+    blocks = bench.timed_blocks(fake_block, 7, 1e9, 5, sync, lambda x: 0.3)
+    assert len(blocks) == 5                                                             # capped
+    cores, quota = bench.host_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1) and (quota is None or quota > 0)
+    assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
