@@ -456,9 +456,11 @@ static void timing_end(rem2d_world *w, hipStream_t st) {
     w->evUsed += 1;
 }
 
+static void graphs_forget(const rem2d_world *w); // (the hipGraph replays of rem2d_groups_step, below)
 extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (!w) return REM2D_OK;
     (void)hipSetDevice(w->cfg.device);
+    graphs_forget(w);
     free_timing(w);
     if (w->evFork) (void)hipEventDestroy(w->evFork);
     if (w->evJoin) (void)hipEventDestroy(w->evJoin);
@@ -800,8 +802,27 @@ struct GraphEntry {
     uint64_t key;
     hipGraphExec_t exec;
     hipGraph_t graph;
+    std::vector<const rem2d_world *> worlds; // whose kernel arguments and fork / join events the replay holds
 };
 static std::vector<GraphEntry> g_graphs;
+static void graph_entry_free(GraphEntry &e) {
+    (void)hipDeviceSynchronize(); // (a replay may still be in flight)
+    (void)hipGraphExecDestroy(e.exec);
+    (void)hipGraphDestroy(e.graph);
+}
+// a world is going away: so must every replay that was captured with it (its events and scratch pointers)
+static void graphs_forget(const rem2d_world *w) {
+    for (size_t i = 0; i < g_graphs.size();) {
+        bool uses = false;
+        for (const rem2d_world *x : g_graphs[i].worlds) uses = uses || x == w;
+        if (uses) {
+            graph_entry_free(g_graphs[i]);
+            g_graphs.erase(g_graphs.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+}
 static hipStream_t g_captureStream = nullptr;
 static uint64_t mix64(uint64_t h, uint64_t v) {
     h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
@@ -917,12 +938,15 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
             (void)hipGraphDestroy(graph);
             return fail(REM2D_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
-        if (g_graphs.size() >= 16) { // worlds come and go (compact(), reset): drop the oldest replay
-            (void)hipGraphExecDestroy(g_graphs.front().exec);
-            (void)hipGraphDestroy(g_graphs.front().graph);
+        if (g_graphs.size() >= 16) { // call lengths come and go: drop the oldest replay
+            graph_entry_free(g_graphs.front());
             g_graphs.erase(g_graphs.begin());
         }
-        g_graphs.push_back({key, exec, graph});
+        GraphEntry ge;
+        ge.key = key; ge.exec = exec; ge.graph = graph;
+        for (int g = 0; g < n_groups; ++g)
+            for (int i = 0; i < groups[g].n_worlds; ++i) ge.worlds.push_back(groups[g].worlds[i]);
+        g_graphs.push_back(ge);
         hit = &g_graphs.back();
     }
     HIP_TRY(hipGraphLaunch(hit->exec, origin));

@@ -273,7 +273,9 @@ def test_full_size_chain8(gpu, oracle, flat_terrain):
     N, steps = 65536, 200
     env = BatchedModular2D(flat=True, flags=_lib.FLAG_CONTINUOUS)
     env.reset_morphology(synthetic.chain_population(N, 8, "left"))
-    assert env._tile_shape_used == 1 and len(env.groups) == 3 and len(env.worlds) == 3
+    import os
+    assert len(env.groups) == 3 and len(env.worlds) == 3
+    assert env._tile_shape_used == 1 or "REM2D_TILE_SHAPE" in os.environ   # (the suite is also run with the shape forced)
     for _ in range(steps // 25):
         env.step(25)
     torch.cuda.synchronize()
