@@ -22,7 +22,12 @@ DEV float vdist2(V2 a, V2 b) { V2 c = vsub(a, b); return vdot(c, c); }
 DEV float fmin32(float a, float b) { return a < b ? a : b; }
 DEV float fmax32(float a, float b) { return a > b ? a : b; }
 DEV float fabs32(float a) { return a > 0.0f ? a : -a; }
-DEV float fclamp(float a, float lo, float hi) { return fmax32(lo, fmin32(a, hi)); }
+// b2Clamp(a, lo, hi) = b2Max(lo, b2Min(a, hi)) for lo <= hi: the median of the three -- one v_med3_f32 instead of two
+// compare / select pairs (each with a wait state for the SGPR condition).  Same bits for every input but a zero: where
+// Box2D's form picks a bound's +0 the median may keep the argument's -0; a zero stays a zero through everything that
+// follows (sums, products, comparisons against 0 -- there is no division by it), and -0 == +0 in every comparison the
+// tests make (the digests add +0.0 first).
+DEV float fclamp(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
 DEV V2 vmin2(V2 a, V2 b) { return mk(fmin32(a.x, b.x), fmin32(a.y, b.y)); }
 DEV V2 vmax2(V2 a, V2 b) { return mk(fmax32(a.x, b.x), fmax32(a.y, b.y)); }
 DEV float vnormalize(V2 &a) {
