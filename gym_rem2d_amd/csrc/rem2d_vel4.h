@@ -144,7 +144,9 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
             j.impX += ix; j.impY += iy; j.impZ += iz;
         } else {
             float newImpulse = j.impZ + iz;
-            bool reduce = limitState == LIM_AT_LOWER ? newImpulse < 0.0f : newImpulse > 0.0f;
+            // (at the lower limit the impulse may not go negative, at the upper not positive: one comparison of the
+            // impulse or its negation -- x > 0 <=> -x < 0, also for the zeros -- instead of two compares and a select)
+            bool reduce = (limitState == LIM_AT_LOWER ? newImpulse : -newImpulse) < 0.0f;
             if (reduce) {
                 V2 rhs = vadd(vneg(Cdot1), vscale(j.impZ, mk(ezx, ezy)));
                 float rx = j.det22 * (j.eyy * rhs.x - j.eyx * rhs.y);
