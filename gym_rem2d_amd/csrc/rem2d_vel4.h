@@ -127,11 +127,16 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
         wA -= iA * impulse;
         wB += iB * impulse;
     }
+    // (the relative velocity of the anchors and the application of the impulse are common to the limit (3 x 3) and the point
+    // (2 x 2) solve: a wavefront usually holds joints of both kinds and runs both branches one after the other, so what
+    // they share is computed once.  For a joint without an active limit the angular impulse is a literal 0 added to the
+    // cross products -- x + 0 is x, bar the sign of a zero.)
+    const V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
+    float ix, iy, iz = 0.0f;
     if (limitState != LIM_INACTIVE) {
         // ex = (exx, eyx, ezx), ey = (eyx, eyy, ezy), ez = (ezx, ezy, ezz) of m_mass; cyz = cross(ey, ez)
         const float ezx = j.ezx, ezy = j.ezy, ezz = iA + iB;
         const float cyzx = j.cyzx, cyzy = j.cyzy, cyzz = j.cyzz;
-        V2 Cdot1 = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
         float Cdot2 = wB - wA;
         float bx = Cdot1.x, by = Cdot1.y, bz = Cdot2;
         float sx = j.det33 * (bx * cyzx + by * cyzy + bz * cyzz);
@@ -139,7 +144,7 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
         float sy = j.det33 * (j.exx * cbx + j.eyx * cby + ezx * cbz);
         float ebx = j.eyy * bz - ezy * by, eby = ezy * bx - j.eyx * bz, ebz = j.eyx * by - j.eyy * bx;
         float sz = j.det33 * (j.exx * ebx + j.eyx * eby + ezx * ebz);
-        float ix = -sx, iy = -sy, iz = -sz;
+        ix = -sx; iy = -sy; iz = -sz;
         if (limitState == LIM_EQUAL) {
             j.impX += ix; j.impY += iy; j.impZ += iz;
         } else {
@@ -157,20 +162,18 @@ template <typename SH> DEV void v4_joint_slot(JointT &j, SH &sh) {
                 j.impX += ix; j.impY += iy; j.impZ += iz;
             }
         }
+    } else {
+        V2 bb = vneg(Cdot1);
+        ix = j.det22 * (j.eyy * bb.x - j.eyx * bb.y);
+        iy = j.det22 * (j.exx * bb.y - j.eyx * bb.x);
+        j.impX += ix; j.impY += iy;
+    }
+    {
         V2 P = mk(ix, iy);
         vA = vsub(vA, vscale(j.mA, P));
         wA -= iA * (vcross(j.rA, P) + iz);
         vB = vadd(vB, vscale(j.mB, P));
         wB += iB * (vcross(j.rB, P) + iz);
-    } else {
-        V2 Cdot = vsub(vsub(vadd(vB, vcross_sv(wB, j.rB)), vA), vcross_sv(wA, j.rA));
-        V2 bb = vneg(Cdot);
-        V2 impulse = mk(j.det22 * (j.eyy * bb.x - j.eyx * bb.y), j.det22 * (j.exx * bb.y - j.eyx * bb.x));
-        j.impX += impulse.x; j.impY += impulse.y;
-        vA = vsub(vA, vscale(j.mA, impulse));
-        wA -= iA * vcross(j.rA, impulse);
-        vB = vadd(vB, vscale(j.mB, impulse));
-        wB += iB * vcross(j.rB, impulse);
     }
     ra.x = vA.x; ra.y = vA.y; ra.w = wA;
     rb.x = vB.x; rb.y = vB.y; rb.w = wB;
