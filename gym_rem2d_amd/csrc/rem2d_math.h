@@ -19,8 +19,11 @@ DEV V2 vcross_vs(V2 a, float s) { return mk(s * a.y, -s * a.x); }
 DEV V2 vcross_sv(float s, V2 a) { return mk(-s * a.y, s * a.x); }
 DEV float vlen(V2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
 DEV float vdist2(V2 a, V2 b) { V2 c = vsub(a, b); return vdot(c, c); }
-DEV float fmin32(float a, float b) { return a < b ? a : b; }
-DEV float fmax32(float a, float b) { return a > b ? a : b; }
+// b2Min / b2Max (a < b ? a : b, a > b ? a : b) as the median with -inf / +inf: one v_med3_f32 instead of a compare, a wait
+// state and a select.  The same value for every pair of numbers; of two zeros of different sign the other one may come
+// out (see fclamp below).
+DEV float fmin32(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+DEV float fmax32(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 DEV float fabs32(float a) { return a > 0.0f ? a : -a; }
 // b2Clamp(a, lo, hi) = b2Max(lo, b2Min(a, hi)) for lo <= hi: the median of the three -- one v_med3_f32 instead of two
 // compare / select pairs (each with a wait state for the SGPR condition).  Same bits for every input but a zero: where
