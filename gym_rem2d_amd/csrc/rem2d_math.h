@@ -86,11 +86,12 @@ DEV Rot rot_set(float x) {
     float z = r * r;
     float ps = r + r * (z * (S1 + z * (S2 + z * S3)));
     float pc = (1.0f - 0.5f * z) + z * z * (C1 + z * (C2 + z * C3));
-    int q = n & 3;
-    float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    float ss = (n & 1) ? pc : ps, cc = (n & 1) ? ps : pc;
     Rot o;
-    o.s = (q == 2 || q == 3) ? -ss : ss;
-    o.c = (q == 1 || q == 2) ? -cc : cc;
+    // quadrants 2, 3 negate the sine, quadrants 1, 2 the cosine: the sign bit flipped by bit 1 of n / of n + 1 (the same
+    // bits as the compare-and-select form, in three integer instructions each)
+    o.s = __uint_as_float(__float_as_uint(ss) ^ (((unsigned)n & 2u) << 30));
+    o.c = __uint_as_float(__float_as_uint(cc) ^ ((((unsigned)n + 1u) & 2u) << 30));
     return o;
 }
 DEV double dev_sin(double x) {
