@@ -19,6 +19,8 @@
 // A 60-iteration creature costs 60*period ticks instead of 60*rounds rounds (3x fewer for 16 modules).
 // ---------------------------------------------------------------------------------------------------
 #define POS_RING 8
+// max { y : sqrtf(y) <= b2_linearSlop (0.005f) } (tests/test_host_golden.py checks the literal against numpy's sqrt)
+#define POS_SLOP_SQ_MAX 0x1.a36e3p-16f
 struct __attribute__((aligned(16))) PosRec { float x, y, a, pad; }; // one body's position: one 16-byte LDS access
 struct PosShared {
     union {
@@ -223,7 +225,9 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 V2 prA = rmul(qA, vsub(anchorA, mk(0.0f, 0.0f)));
                 V2 prB = rmul(qB, vsub(anchorB, mk(0.0f, 0.0f)));
                 V2 C = vsub(vsub(vadd(cB, prB), cA), prA);
-                positionError = vlen(C);
+                // (only compared with b2_linearSlop below: |C| <= slop <=> C.C <= the largest binary32 whose correctly rounded
+                // square root is <= slop -- sqrt is monotone -- which spares the square root's ten instructions)
+                positionError = vdot(C, C);
                 float Kexx = mA + mB + iA * prA.y * prA.y + iB * prB.y * prB.y;
                 float Kexy = -iA * prA.x * prA.y - iB * prB.x * prB.y;
                 float Keyy = mA + mB + iA * prA.x * prA.x + iB * prB.x * prB.x;
@@ -241,7 +245,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             outB.x = cB.x; outB.y = cB.y; outB.a = aB; outB.pad = 0.0f;
             sh.pos[pl] = outA;
             sh.pos[lane] = outB;
-            if (!(positionError <= B2_LINEAR_SLOP && angularError <= B2_ANGULAR_SLOP)) failBits |= 1ull << (itJ & 63);
+            if (!(positionError <= POS_SLOP_SQ_MAX && angularError <= B2_ANGULAR_SLOP)) failBits |= 1ull << (itJ & 63);
             const int r = itJ & (POS_RING - 1);
             if (isLastA) sh.snap[r][pl] = outA;
             if (isLastB) sh.snap[r][lane] = outB;

@@ -297,3 +297,21 @@ def test_morphology_concat_take_and_uniform_population_detection():
     assert not _uniform(m)
     assert _uniform(synthetic.chain_population(50, 8, "left"))
     assert _uniform(Morphology.replicate(specs[3], 7, 16))
+
+
+def test_position_error_threshold_constant():
+    """rem2d_position.h compares the SQUARED joint position error with POS_SLOP_SQ_MAX instead of taking the square root:
+    the literal must be the largest binary32 y with sqrtf(y) <= b2_linearSlop (0.005f), so that the test decides exactly
+    like b2RevoluteJoint::SolvePositionConstraints' `positionError <= b2_linearSlop` (sqrt is monotone)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "gym_rem2d_amd", "csrc", "rem2d_position.h")).read()
+    lit = re.search(r"#define POS_SLOP_SQ_MAX (0x[0-9a-fp.\-]+)f", src).group(1)
+    y = np.float32(float.fromhex(lit))
+    slop = np.float32(0.005)
+    assert float(y) == float.fromhex(lit)                                    # the literal is a binary32 value
+    assert np.sqrt(y, dtype=np.float32) <= slop
+    assert np.sqrt(np.nextafter(y, np.float32(1), dtype=np.float32), dtype=np.float32) > slop
+    rng = np.random.default_rng(0)
+    x = (rng.random(200000, dtype=np.float32) * np.float32(6e-5)).astype(np.float32)
+    assert np.array_equal(np.sqrt(x, dtype=np.float32) <= slop, x <= y)
