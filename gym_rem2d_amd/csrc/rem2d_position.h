@@ -19,6 +19,7 @@
 // A 60-iteration creature costs 60*period ticks instead of 60*rounds rounds (3x fewer for 16 modules).
 // ---------------------------------------------------------------------------------------------------
 #define POS_RING 8
+static_assert(POS_RING <= 32, "the failure bits of the iterations in flight live in one 32-bit word");
 // max { y : sqrtf(y) <= b2_linearSlop (0.005f) } (tests/test_host_golden.py checks the literal against numpy's sqrt)
 #define POS_SLOP_SQ_MAX 0x1.a36e3p-16f
 struct __attribute__((aligned(16))) PosRec { float x, y, a, pad; }; // one body's position: one 16-byte LDS access
@@ -150,7 +151,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     int nextC = (run && touching) ? (offC > 0 ? offC : 0) : 0x7fffffff, leftC = posIters, itC = 0;
     int nextJ = (run && hasJoint) ? jround + rot : 0x7fffffff, leftJ = posIters, itJ = 0;
     int nextD = run ? maxR + rot : 0x7fffffff, itD = 0;
-    unsigned long long failBits = 0ull;
+    unsigned failBits = 0u; // a ring of POS_RING (<= 32) iterations in flight: one 32-bit word
     const int lastTick = wave_max(run ? maxR + rot + (posIters - 1) * P : -1);
     { PosRec r0; r0.x = px; r0.y = py; r0.a = ang; r0.pad = 0.0f; sh.pos[lane] = r0; }
     lds_sync();
@@ -179,7 +180,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                 pos_manifold_load(S, gl, t, m);
                 pos_solve_manifold(m, mB, iB, radiusB, cx, cy, ca, minSeparation);
             }
-            if (!(minSeparation >= -3.0f * B2_LINEAR_SLOP)) failBits |= 1ull << (itC & 63);
+            if (!(minSeparation >= -3.0f * B2_LINEAR_SLOP)) failBits |= 1u << (itC & 31);
             PosRec out; out.x = cx; out.y = cy; out.a = ca; out.pad = 0.0f;
             sh.pos[lane] = out;
             if (!anyJoint) { // the contact slot is this body's last operation of the iteration
@@ -245,7 +246,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             outB.x = cB.x; outB.y = cB.y; outB.a = aB; outB.pad = 0.0f;
             sh.pos[pl] = outA;
             sh.pos[lane] = outB;
-            if (!(positionError <= POS_SLOP_SQ_MAX && angularError <= B2_ANGULAR_SLOP)) failBits |= 1ull << (itJ & 63);
+            if (!(positionError <= POS_SLOP_SQ_MAX && angularError <= B2_ANGULAR_SLOP)) failBits |= 1u << (itJ & 31);
             const int r = itJ & (POS_RING - 1);
             if (isLastA) sh.snap[r][pl] = outA;
             if (isLastB) sh.snap[r][lane] = outB;
@@ -258,10 +259,10 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         const bool due = tick == nextD;
         if (__any(due ? 1 : 0)) { // (a wavefront whose only unfinished creature has period P is due once in P ticks)
             // (one ballot and the creature's lane mask instead of a K-lane shuffle reduction in every tick)
-            const unsigned long long failedLanes = __ballot(due && ((failBits >> (itD & 63)) & 1ull) != 0ull);
+            const unsigned long long failedLanes = __ballot(due && ((failBits >> (itD & 31)) & 1u) != 0u);
             const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
             const bool failed = (failedLanes & groupLanes) != 0ull;
-            if (due) failBits &= ~(1ull << (itD & 63)); // the mask is a ring: at most POS_RING iterations are in flight
+            if (due) failBits &= ~(1u << (itD & 31)); // the mask is a ring: at most POS_RING iterations are in flight
             bool restored = false;
             if (due) {
                 if (!failed) { // Box2D breaks here: drop whatever later iterations have already done
