@@ -100,6 +100,11 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
                                    bool &envSolved, int &itersUsed) {
     const V2 anchorA = mk(LF(L_JAX), LF(L_JAY)), anchorB = mk(LF(L_JBX), LF(L_JBY));
     const float jLower = LF(L_JLOWER), jUpper = LF(L_JUPPER);
+    // the limit case of this lane's joint as constants of the iteration loop (see the joint slot)
+    const float limRef = limitState == LIM_AT_UPPER ? jUpper : jLower;
+    const float limOff = limitState == LIM_AT_LOWER ? B2_ANGULAR_SLOP : (limitState == LIM_AT_UPPER ? -B2_ANGULAR_SLOP : 0.0f);
+    const float limLo = limitState == LIM_AT_UPPER ? 0.0f : -B2_MAX_ANGULAR_CORRECTION;
+    const float limHi = limitState == LIM_AT_LOWER ? 0.0f : B2_MAX_ANGULAR_CORRECTION;
     PosManifold pm[POS_KR];
 #pragma unroll
     for (int t = 0; t < POS_KR; ++t) {
@@ -201,23 +206,18 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
             float aB = recB.a;
             float angularError = 0.0f, positionError = 0.0f;
             if (limitState != LIM_INACTIVE) {
+                // b2RevoluteJoint::SolvePositionConstraints' three limit cases as ONE instruction sequence (a wavefront
+                // usually holds joints at their lower and at their upper limit and would run the cases one after the other):
+                //   equal:  C = clamp(angle - lower,        -maxCorr, maxCorr), error = |C|
+                //   lower:  C = clamp(angle - lower + slop, -maxCorr, 0),       error = -(angle - lower)
+                //   upper:  C = clamp(angle - upper - slop,  0, maxCorr),       error =   angle - upper
+                // with the per-joint constants (reference angle, slop term, clamp bounds) picked before the loop.  Same
+                // operations on the same operands; the equal case adds a literal 0 (x + 0 is x bar the sign of a zero).
                 float angle = aB - aA - 0.0f;
-                float limitImpulse = 0.0f;
-                if (limitState == LIM_EQUAL) {
-                    float C = fclamp(angle - jLower, -B2_MAX_ANGULAR_CORRECTION, B2_MAX_ANGULAR_CORRECTION);
-                    limitImpulse = -motorMass * C;
-                    angularError = fabs32(C);
-                } else if (limitState == LIM_AT_LOWER) {
-                    float C = angle - jLower;
-                    angularError = -C;
-                    C = fclamp(C + B2_ANGULAR_SLOP, -B2_MAX_ANGULAR_CORRECTION, 0.0f);
-                    limitImpulse = -motorMass * C;
-                } else {
-                    float C = angle - jUpper;
-                    angularError = C;
-                    C = fclamp(C - B2_ANGULAR_SLOP, 0.0f, B2_MAX_ANGULAR_CORRECTION);
-                    limitImpulse = -motorMass * C;
-                }
+                const float C0 = angle - limRef;
+                const float C = fclamp(C0 + limOff, limLo, limHi);
+                const float limitImpulse = -motorMass * C;
+                angularError = limitState == LIM_EQUAL ? fabs32(C) : (limitState == LIM_AT_LOWER ? -C0 : C0);
                 aA -= iA * limitImpulse;
                 aB += iB * limitImpulse;
             }
