@@ -277,7 +277,7 @@ DEV void step_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
                 lds_sync();
                 int nextJ = (hasJoint && iters > 0) ? jround : 0x7fffffff, leftJ = iters;
                 int nextC = (active && nTouch > 0 && iters > 0) ? offC : 0x7fffffff, leftC = iters;
-                const int nTicks = wave_max((active && iters > 0) ? offC + (iters - 1) * period : -1) + 1;
+                const int nTicks = wave_max_active((active && iters > 0) ? offC + (iters - 1) * period + 1 : 0, 16); // (under `if (envAwake)`)
                 for (int tick = 0; tick < nTicks; ++tick) {
                     if (tick == nextJ) {
                         nextJ = (--leftJ > 0) ? nextJ + period : 0x7fffffff;

@@ -136,13 +136,29 @@ DEV void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
+// the same for code that only SOME lanes of the wavefront execute (a shuffle would read the registers of the inactive lanes):
+// the maximum of 0 <= v < 2^bits over the ACTIVE lanes, bit by bit from the top with ballots; a scalar.
+DEV int wave_max_active(int v, int bits) {
+    int r = 0;
+    bool cand = true;
+    for (int b = bits - 1; b >= 0; --b) {
+        const bool has = cand && ((v >> b) & 1) != 0;
+        if (__ballot(has)) { // some candidate has this bit: the maximum has it, candidates without it drop out
+            r |= 1 << b;
+            cand = has;
+        }
+    }
+    return r;
+}
 DEV int wave_max(int v) {
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
         int t = __shfl_xor(v, o);
         v = t > v ? t : v;
     }
-    return v;
+    // (every lane holds the same value now: hand it out as a scalar, so that the loops and branches it controls are
+    // scalar loops and branches instead of lane-mask juggling around every slot of the solver loops)
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 #endif

@@ -198,12 +198,12 @@ __global__ __launch_bounds__(WAVE) void rem2d_pre_multi_kernel(Batch B, StepArgs
 DEV int wave_sum(int v) {
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) v += __shfl_xor(v, o);
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 DEV int wave_or(int v) {
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) v |= __shfl_xor(v, o);
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // ---------------------------------------------------------------------------------------------------

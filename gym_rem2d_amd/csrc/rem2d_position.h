@@ -139,7 +139,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     const unsigned long long groupLanes = (K == WAVE ? ~0ull : ((1ull << (K & 63)) - 1ull)) << (lane & ~(K - 1));
     int offC = hiC, rot = 0;
     {
-        const int Pw = wave_max(P);
+        const int Pw = wave_max_active(P, 8); // (this function runs under `if (envAwake)`: not every lane is here)
         int best = 0, bestPhase = 0;
         for (int c = 0; c < Pw; ++c) { // (per creature: the ballots are masked with its lanes)
             int d = (c - loC) % P;
@@ -157,7 +157,7 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
     int nextJ = (run && hasJoint) ? jround + rot : 0x7fffffff, leftJ = posIters, itJ = 0;
     int nextD = run ? maxR + rot : 0x7fffffff, itD = 0;
     unsigned failBits = 0u; // a ring of POS_RING (<= 32) iterations in flight: one 32-bit word
-    const int lastTick = wave_max(run ? maxR + rot + (posIters - 1) * P : -1);
+    const int lastTick = wave_max_active(run ? maxR + rot + (posIters - 1) * P + 1 : 0, 16) - 1;
     { PosRec r0; r0.x = px; r0.y = py; r0.a = ang; r0.pad = 0.0f; sh.pos[lane] = r0; }
     lds_sync();
 #ifdef REM2D_POS_STAMPS // diagnostic build (tools/pos_stamps_probe.py): where the cycles of a wavefront's tick loop go
