@@ -354,7 +354,10 @@ extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jrou
     if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
     if (max_creatures <= 0) {
         static const int envCap = getenv("REM2D_TILE_CREATURES") ? atoi(getenv("REM2D_TILE_CREATURES")) : 0;
-        max_creatures = envCap > 0 ? envCap : 16; // (two-lane creatures, 32 to a tile, are faster 16 to a tile: 46.8 vs 46.4 M on config 3)
+        // (64-lane tiles: two-lane creatures, 32 to a tile, are faster 16 to a tile -- 46.8 vs 46.4 M on config 3, 55 vs 49 M on
+        // config 4; the wider shapes are taken where instruction issue limits, and more tiles are more instructions)
+        const int shapeId = tile_shape_sel < 0 ? tile_shape_id() : tile_shape_sel;
+        max_creatures = envCap > 0 ? envCap : (shapeId == 3 ? 16 : 32);
     }
     const int capBodies = maxLanes / lanes; // creatures per tile by lanes
     const int cap = max_creatures < capBodies ? max_creatures : capBodies;
