@@ -82,10 +82,12 @@ DEV Rot rot_set(float x) {
     const float C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
     float fn = rintf(x * TWO_OVER_PI);
     int n = (int)fn;
-    float r = ((x - fn * DP1) - fn * DP2) - fn * DP3;
+    // (rem2d trig: every step of the reduction and of the two polynomials is ONE fused multiply-add -- a single, exactly
+    // defined rounding each, the same on v_fma_f32 and on the oracle's fmaf)
+    float r = __builtin_fmaf(-fn, DP3, __builtin_fmaf(-fn, DP2, __builtin_fmaf(-fn, DP1, x)));
     float z = r * r;
-    float ps = r + r * (z * (S1 + z * (S2 + z * S3)));
-    float pc = (1.0f - 0.5f * z) + z * z * (C1 + z * (C2 + z * C3));
+    float ps = __builtin_fmaf(r, z * __builtin_fmaf(z, __builtin_fmaf(z, S3, S2), S1), r);
+    float pc = __builtin_fmaf(z * z, __builtin_fmaf(z, __builtin_fmaf(z, C3, C2), C1), __builtin_fmaf(z, -0.5f, 1.0f));
     float ss = (n & 1) ? pc : ps, cc = (n & 1) ? ps : pc;
     Rot o;
     // quadrants 2, 3 negate the sine, quadrants 1, 2 the cosine: the sign bit flipped by bit 1 of n / of n + 1 (the same

@@ -385,7 +385,16 @@ DEV bool post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     return false;
 }
 template <int K> DEV void post_only_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh) {
+#ifdef REM2D_V4_PROBES // diagnostic (tools/chain_probe.py): this wavefront's time in the kernel, in the SECOND creature of its block
+    const unsigned long long rEntry = __builtin_amdgcn_s_memrealtime();
+#endif
     (void)post_body<K, false>(S, T, A, block, psh);
+#ifdef REM2D_V4_PROBES
+    if (threadIdx.x == 0 && 2 * K <= WAVE && !(S.flags & REM2D_FLAG_RETILE)) {
+        const unsigned env = block * (WAVE / K) + 1;
+        if (env < S.Np) EI(E_TOIEVENTS) = (int)(__builtin_amdgcn_s_memrealtime() - rEntry);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArgs A) {

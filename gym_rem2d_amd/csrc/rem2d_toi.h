@@ -529,9 +529,12 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
     const float coreR = shape == SHAPE_BOX ? sqrtf(hx * hx + hy * hy) : 0.0f; // circumradius of the core shape
 #ifdef REM2D_TOI_STAMPS
     unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk, cyc[5] = {0, 0, 0, 0, 0};
+    int nSweeps = 0, nAlpha = 0, islMax = 0;
 #define TOI_STAMP(i) do { tk = __builtin_amdgcn_s_memtime(); cyc[i] += tk - tk0; tk0 = tk; } while (0)
+#define TOI_COUNT(x) do { x; } while (0)
 #else
 #define TOI_STAMP(i) do {} while (0)
+#define TOI_COUNT(x) do {} while (0)
 #endif
     for (;;) {
         int minSlot = -1;
@@ -556,6 +559,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                     int state;
                     float t;
                     time_of_impact(state, t, pA, pB, sw);
+                    TOI_COUNT(nAlpha += 1);
                     float beta = t;
                     if (state == TOI_TOUCHING) alpha = fmin32(alpha0 + (1.0f - alpha0) * beta, 1.0f);
                     else alpha = 1.0f;
@@ -619,6 +623,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
             island_store(ts, lane, nIsl, mo);
             ++nIsl;
         }
+        TOI_COUNT(islMax = max(islMax, nIsl));
         TOI_STAMP(1); // contact updates (TOI contact + the body's other pairs)
         // ---- b2Island::SolveTOI ----
         float cx = sw.c.x, cy = sw.c.y, ca = sw.a;
@@ -704,6 +709,7 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
                 const bool isY = (lane & 1) != 0;
                 float vq = isY ? B.vy : B.vx;
                 for (int it = 0; it < velIters; ++it) {
+                    TOI_COUNT(nSweeps += 1);
                     // Exact early exit: one sweep is a deterministic function of (velocity, impulses); a sweep
                     // that changes no bit is a fixed point, so every later sweep is the identity.  (Single-body
                     // contact-only systems reach it after ~10 sweeps; the full 180 are never needed.)
@@ -827,7 +833,11 @@ DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int s
     {
         unsigned long long tot = 0;
         for (int i = 0; i < 5; ++i) { atomicAdd(&S.toiWork[2 + i], (int)(cyc[i] >> 6)); tot += cyc[i]; }
-        atomicMax(&S.toiWork[8], (int)(tot >> 6));
+        if (atomicMax(&S.toiWork[8], (int)(tot >> 6)) < (int)(tot >> 6)) { // (diagnostic, racy: the split of the longest lane)
+            S.toiWork[12] = (int)(cyc[0] >> 6); S.toiWork[13] = (int)(cyc[3] >> 6);
+            S.toiWork[14] = (int)((cyc[1] + cyc[2] + cyc[4]) >> 6);
+            S.toiWork[15] = nSweeps | (nAlpha << 12) | (B.events << 20) | (islMax << 24) | (G << 27);
+        }
         atomicAdd(&S.toiWork[9], B.events);
         atomicMax(&S.toiWork[10], B.events);
         atomicAdd(&S.toiWork[11], 1);

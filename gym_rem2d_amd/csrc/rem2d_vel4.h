@@ -244,7 +244,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const unsigned Lp = S.Lp;
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
-    const unsigned long long rEntry = (V4_DBG(A) & 16) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
+    const unsigned long long rEntry = (V4_DBG(A) & (16 | 64)) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
     const unsigned tb0 = (unsigned)c0 * (unsigned)K;
     const int iters = A.velIters;
     const float h = A.dt, mu = friction;
@@ -625,6 +625,10 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     if (err && lane == 0) {
         const unsigned env = (unsigned)c0;
         atomicOr(&EI(E_ERR), err);
+    }
+    if ((V4_DBG(A) & 64) && lane == 0) { // diagnostic (tools/chain_probe.py): this wavefront's time in the kernel, 100 MHz ticks
+        const unsigned env = (unsigned)c0;
+        EI(E_TOIEVENTS) = (int)(__builtin_amdgcn_s_memrealtime() - rEntry);
     }
     if ((V4_DBG(A) & 16) && lane == 0 && c1 - c0 >= 2) { // diagnostic: when did this wavefront start and end (tools/dispatch_probe.py)
         unsigned env = (unsigned)c0;

@@ -17,8 +17,9 @@
  *
  * All engine arithmetic is IEEE binary32 without fused multiply-add (build with
  * -ffp-contract=off), evaluated in the operand order of the Box2D expressions.
- * sinf/cosf are replaced by one documented algorithm (o_sincosf) so that the
- * HIP path can reproduce it bit for bit; Python's math.sin by o_sin.
+ * sinf/cosf are replaced by one documented algorithm (rem2d_oracle_sincosf, built
+ * from explicit fmaf steps) so that the HIP path can reproduce it bit for bit;
+ * Python's math.sin by o_sin.
  */
 #include "rem2d_oracle.h"
 
@@ -154,9 +155,17 @@ static void o_sincos_d(double x, double *s, double *c) {
     }
 }
 /* b2Rot::Set: Box2D calls libm sinf/cosf, whose bits are platform specific.  "rem2d trig", binary32
- * form: n = rintf(x*2/pi); r = ((x - n*DP1) - n*DP2) - n*DP3 (Cody-Waite, pi/2 in three parts);
- * Cephes sinf/cosf polynomials on [-pi/4, pi/4]; every operation is a separately rounded binary32
- * operation.  Within ~1 ulp of libm for |x| < 1e3 (tests/test_oracle_kat.py). */
+ * form: n = rintf(x*2/pi); r = x - n*DP1 - n*DP2 - n*DP3 (Cody-Waite, pi/2 in three parts); Cephes
+ * sinf/cosf polynomials on [-pi/4, pi/4] in Horner form.  Every step of the reduction and of the
+ * polynomials is ONE fused multiply-add (fmaf: a single, exactly defined rounding -- the same bits from
+ * the hardware instruction, from libm's software fallback and from the GPU's v_fma_f32); this is the
+ * only place where the engine arithmetic fuses anything.  Within ~1 ulp of libm for |x| < 1e3
+ * (tests/test_oracle_kat.py).  (Round 3: the separately rounded multiply / add form it replaces cost
+ * the HIP path 11 more instructions per b2Rot::Set, of which the position solver runs two per joint and
+ * one per manifold point in every iteration.) */
+#if defined(__GNUC__) && defined(__x86_64__) && !defined(__clang__)
+__attribute__((target_clones("fma", "default")))
+#endif
 void rem2d_oracle_sincosf(float x, float *s, float *c) {
     const float TWO_OVER_PI = 0.63661977236758134308f;
     const float DP1 = 1.5703125f, DP2 = 4.837512969970703125e-4f, DP3 = 7.54978995489188216e-8f;
@@ -164,10 +173,10 @@ void rem2d_oracle_sincosf(float x, float *s, float *c) {
     const float FC1 = 4.166664568298827e-2f, FC2 = -1.388731625493765e-3f, FC3 = 2.443315711809948e-5f;
     float fn = rintf(x * TWO_OVER_PI);
     int n = (int)fn;
-    float r = ((x - fn * DP1) - fn * DP2) - fn * DP3;
+    float r = fmaf(-fn, DP3, fmaf(-fn, DP2, fmaf(-fn, DP1, x)));
     float z = r * r;
-    float ps = r + r * (z * (FS1 + z * (FS2 + z * FS3)));
-    float pc = (1.0f - 0.5f * z) + z * z * (FC1 + z * (FC2 + z * FC3));
+    float ps = fmaf(r, z * fmaf(z, fmaf(z, FS3, FS2), FS1), r);
+    float pc = fmaf(z * z, fmaf(z, fmaf(z, FC3, FC2), FC1), fmaf(z, -0.5f, 1.0f));
     switch (n & 3) {
     case 0: *s = ps; *c = pc; break;
     case 1: *s = pc; *c = -ps; break;

@@ -33,4 +33,7 @@ for m in morphs:
           % (m.lanes, v[11] / steps, v[9] / max(1, v[11]), v[10], v[8] * 64 / 1e3, steps))
     for n, c in zip(names, cyc):
         print("      %-40s %5.1f %%   %.1f kcycles per heavy body" % (n, 100 * c / cyc.sum(), c / max(1, v[11]) / 1e3))
+    x = int(v[15])
+    print("      longest lane: alpha pass %.0f, velocity %.0f, rest %.0f kcycles; %d sweeps, %d b2TimeOfImpact calls, %d events, island of %d, %d lanes per body"
+          % (v[12] * 64 / 1e3, v[13] * 64 / 1e3, v[14] * 64 / 1e3, x & 0xfff, (x >> 12) & 0xff, (x >> 20) & 0xf, (x >> 24) & 7, x >> 27))
     w.close()

@@ -49,6 +49,20 @@ def main():
     for n, v in sorted(per.items()):
         print("  %-50s n=%4d avg %.4f ms max %.4f ms" % (n[:50], len(v), sum(v) / len(v) / 1e6, max(v) / 1e6))
     print("dispatches per queue: " + ", ".join("%s: %d" % kv for kv in sorted(q.items())))
+    # per queue (= step group): its own kernels' average durations and the time from one pre to the next (its step)
+    byq = defaultdict(list)
+    for r in rows:
+        byq[r[3]].append(r)
+    for qu, rs in sorted(byq.items()):
+        kd = defaultdict(list)
+        for s, e, n, _ in rs:
+            kd[n.split("<")[0].replace("rem2d_", "").replace("_multi_kernel", "").replace("_kernel", "")].append((e - s) / 1e3)
+        starts = [s for s, e, n, _ in rs if "pre_multi" in n]
+        per = [(b - a) / 1e3 for a, b in zip(starts, starts[1:])]
+        per.sort()
+        print("  queue %s: %s | pre-to-pre median %.0f us, p90 %.0f, max %.0f" % (
+            qu, ", ".join("%s avg %.0f p90 %.0f max %.0f us" % (k, sum(v) / len(v), sorted(v)[int(0.9 * (len(v) - 1))], max(v)) for k, v in sorted(kd.items())),
+            per[len(per) // 2] if per else 0, per[int(0.9 * (len(per) - 1))] if per else 0, per[-1] if per else 0))
 
 
 if __name__ == "__main__":
