@@ -335,6 +335,15 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
     w->tilesDev = dev;
     w->nTiles = n_tiles;
     w->S.tiles = dev;
+    // a regular table (tile t = creatures [t cap, (t + 1) cap), cap dividing the creatures of a 64-lane block): the
+    // velocity + position launch can find the tiles of a block
+    {
+        const int cap = tile_start[1] - tile_start[0], cpb = WAVE / w->cfg.lanes;
+        bool regular = w->cfg.lanes <= WAVE && cap > 0 && cpb % cap == 0 && tile_start[n_tiles] <= n_tiles * cap;
+        for (int t = 0; t < n_tiles && regular; ++t) regular = tile_start[t] == t * cap;
+        w->S.nTiles = n_tiles;
+        w->S.tileCap = regular ? cap : 0;
+    }
     w->epoch = next_epoch();
     return REM2D_OK;
 }
@@ -609,6 +618,14 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
 // REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = the fused
 // rem2d_step_kernel of round 1 (one body per lane for the whole step) -- kept as an independently written second
 // formulation that the parity suite runs against the same oracle.
+// REM2D_FUSE_VELPOST=1: velocity iterations and post in one launch where the tile tables allow it (rem2d_velpost_kernel).
+// Measured +1.0 % on config 3 (47.8 vs 47.4 M: the slowest velocity tile is usually the slowest position block as well, so
+// max(v + p) is hardly less than max v + max p); off by default -- the per-phase launches keep the per-kernel timings and
+// profiles of the rounds comparable.
+static bool fuse_velpost() {
+    static const bool on = getenv("REM2D_FUSE_VELPOST") && atoi(getenv("REM2D_FUSE_VELPOST")) == 1;
+    return on;
+}
 static int pipeline_mode() {
     static const int mode = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 3;
     return mode == 0 ? 0 : 3;
@@ -625,6 +642,7 @@ struct TilePlan {
     unsigned blocks, tiles;
     int launchShape;
     bool continuous;
+    bool velpost; // one launch for the velocity iterations and post (rem2d_velpost_kernel)
     rem2d_world *w0;
 };
 static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float dt, int vel_iters, int pos_iters) {
@@ -665,6 +683,9 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
         const int id = ws[i]->tileShape;
         if (id == 0 || (id == 1 && P.launchShape == 3)) P.launchShape = id;
     }
+    P.velpost = fuse_velpost() && P.launchShape == 3;
+    for (int i = 0; i < n_worlds; ++i)
+        P.velpost = P.velpost && ws[i]->S.tileCap > 0 && !(ws[i]->cfg.flags & REM2D_FLAG_RETILE) && ws[i]->tileShape == 3;
     P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     P.A.nSteps = 1;
     P.A.dt = dt;
@@ -689,22 +710,32 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
                            hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
     hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, P.B, P.A);
     const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
-    if (timed) {
-        hipEvent_t e0 = w0->evPool[w0->evUsed].first, e1 = w0->evPool[w0->evUsed].second;
-        switch (P.launchShape) {
-        case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-        case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-        default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+    if (P.velpost) {
+        if (timed) {
+            hipExtLaunchKernelGGL(rem2d_velpost_kernel, grid, block, 0, st, w0->evPool[w0->evUsed].first, w0->evPool[w0->evUsed].second, 0,
+                                  P.B, P.A, P.V);
+            w0->evUsed += 1;
+        } else {
+            hipLaunchKernelGGL(rem2d_velpost_kernel, grid, block, 0, st, P.B, P.A, P.V);
         }
-        w0->evUsed += 1;
     } else {
-        switch (P.launchShape) {
-        case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-        case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-        default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+        if (timed) {
+            hipEvent_t e0 = w0->evPool[w0->evUsed].first, e1 = w0->evPool[w0->evUsed].second;
+            switch (P.launchShape) {
+            case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            }
+            w0->evUsed += 1;
+        } else {
+            switch (P.launchShape) {
+            case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            }
         }
+        hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, P.B, P.A);
     }
-    hipLaunchKernelGGL(rem2d_post_multi_kernel, grid, block, 0, st, P.B, P.A);
     if (P.continuous) hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, P.B, P.A);
     if (timedStep) {
         (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);

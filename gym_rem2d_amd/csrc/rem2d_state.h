@@ -91,6 +91,9 @@ struct State {
     unsigned char *outDone;
     const int *outIndex;
     unsigned Lp, Np, nEnvs, flags;
+    // the tile table's shape when it is regular (every tile tileCap creatures, tileCap dividing a 64-lane block): the
+    // velocity + position launch (rem2d_velpost_kernel) finds the tiles of a block with it; 0 = irregular table
+    int nTiles, tileCap;
 };
 // accessors (S, gl and env must be in scope where they are used)
 #define LF(f) (*(float *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))

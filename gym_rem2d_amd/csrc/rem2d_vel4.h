@@ -40,6 +40,7 @@ struct Vel4Args { int velIters; float dt; int dbg; /* diagnostic builds (-DREM2D
 #define V4_DBG(A) ((A).dbg)
 #else
 #define V4_DBG(A) 0
+
 #endif
 
 struct __attribute__((aligned(16))) V4Vel { float x, y, w, invI; };
@@ -653,6 +654,40 @@ __global__ __launch_bounds__(WAVE, WPS) void rem2d_vel4_kernel(Vel4Batch B, Vel4
     while (b + 1 < B.n && tile >= B.tileEnd[b]) ++b;
     if (b > 0) tile -= B.tileEnd[b - 1];
     vel4_body<SETS, PASSES, CSETS, CPAIR>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// velocity iterations + post in ONE launch (64-lane tiles whose table is regular: State::tileCap).  The launch of a phase
+// lasts as long as its slowest wavefront, and the slowest tile of the velocity kernel is usually not the slowest block
+// of the position kernel: one wavefront doing both for its 64 lanes costs the launch max(v + p) instead of max v + max p
+// (tools/chain_probe.py: 5 % less on config 3's widest lane bucket alone in a launch; 2 % in the mix of a step group), and
+// one launch gap less.  Same device functions, same order per creature: same bits.  128 VGPRs, no spills, 4 waves per
+// SIMD -- with the velocity half inlined ONCE, in front of the lane-count dispatch of the position half (inside every case
+// of it: 66 spilled VGPRs).  Optional (REM2D_FUSE_VELPOST=1, rem2d.hip): +1.0 % on config 3.
+// ---------------------------------------------------------------------------------------------------
+struct VelPostShared {
+    union {
+        Vel4Shared<1, 1> v;
+        PosShared p;
+    };
+};
+__global__ __launch_bounds__(WAVE, 4) void rem2d_velpost_kernel(Batch B, StepArgs A, Vel4Args V) {
+    __shared__ VelPostShared sh;
+    unsigned block = blockIdx.x;
+    const int b = batch_find(B, block);
+    {
+        const int K = B.lanes[b];
+        const unsigned cpb = (unsigned)(WAVE / K), cap = (unsigned)B.S[b].tileCap; // creatures per block / per tile; cap divides cpb (host)
+        const unsigned t1 = (block + 1) * cpb / cap;
+        for (unsigned t = block * cpb / cap; t < t1 && t < (unsigned)B.S[b].nTiles; ++t) {
+            vel4_body<1, 1, 1, true>(B.S[b], B.T[b].friction, V, t, K, sh.v);
+            lds_sync(); // (the next tile / the position solver reuse the mailbox)
+        }
+    }
+    // the velocities, written per tile lane, are read per block lane below (the same lane unless a block holds several tiles)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    BATCH_DISPATCH(post_only_body, sh.p)
 }
 
 #endif

@@ -393,12 +393,14 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
     assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
 
 
-@pytest.mark.parametrize("variant", [{"REM2D_PIPELINE": "0"}, {"REM2D_TILE_SHAPE": "0"}, {"REM2D_TILE_SHAPE": "1"}],
-                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies"])
+@pytest.mark.parametrize("variant", [{"REM2D_PIPELINE": "0"}, {"REM2D_TILE_SHAPE": "0"}, {"REM2D_TILE_SHAPE": "1"},
+                                     {"REM2D_FUSE_VELPOST": "1"}],
+                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "velocity_and_position_in_one_launch"])
 def test_other_formulations_match_committed_digests(gpu, variant):
     """The library's switches are read once per process, so every other formulation runs in a child process: the fused
     body-per-lane kernel of round 1 (REM2D_PIPELINE=0) and the wider tile shapes of the velocity kernel (256 / 128
-    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default."""
+    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default; so does the
+    launch that runs a block's velocity tiles and its position iterations in one wavefront (rem2d_velpost_kernel)."""
     import json
     import os
     import subprocess
