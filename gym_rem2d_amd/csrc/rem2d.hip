@@ -134,9 +134,11 @@ struct rem2d_world {
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
 //   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
 struct TileShape { int sets, passes, csets; };
-// bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel (rem2d_kernels.h); REM2D_HEAVY_PER_WAVE, 1..64
+// bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel (rem2d_kernels.h); REM2D_HEAVY_PER_WAVE, 1..64.
+// One: a wavefront that holds two runs the union of their code paths (64 -> 8 -> 2 -> 1 bodies: 36.0 -> 37.4 -> 37.9 M in
+// round 2, 47.38 -> 47.55 M for 2 -> 1 now that the sub-step's sweeps are split over a body's lanes).
 static int heavy_per_wave() {
-    static const int n = getenv("REM2D_HEAVY_PER_WAVE") ? atoi(getenv("REM2D_HEAVY_PER_WAVE")) : 2;
+    static const int n = getenv("REM2D_HEAVY_PER_WAVE") ? atoi(getenv("REM2D_HEAVY_PER_WAVE")) : 1;
     return n < 1 ? 1 : (n > WAVE ? WAVE : n);
 }
 static int tile_shape_id() {

@@ -600,7 +600,7 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     // Bodies per wavefront: the lanes of a wavefront run the event loop in lockstep -- every b2TimeOfImpact any lane needs at
     // any pair slot, the 180 sweeps of a sub-step as soon as one lane's does not reach its fixed point, as many rounds as
     // the lane with the most events -- so a full wavefront costs about twice its slowest body.  The list is short (about
-    // 1 % of the bodies): it is dealt out REM2D_HEAVY_PER_WAVE bodies to a wavefront, more only when it is so long that
+    // 1 % of the bodies): it is dealt out REM2D_HEAVY_PER_WAVE bodies (default: one) to a wavefront, more only when it is so long that
     // the grid would not cover it (the landing after a reset).
     const unsigned queued = (unsigned)S.toiWork[0], blocks = S.Lp / WAVE;
     unsigned per = (queued + blocks - 1) / blocks;
