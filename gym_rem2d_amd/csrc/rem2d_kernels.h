@@ -34,7 +34,7 @@ DEV void env_bookkeeping(const State &S, unsigned env, int sub, float rootx) {
 // =====================================================================================
 // the step kernel
 // =====================================================================================
-struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ int heavyPerWave; };
+struct StepArgs { int nSteps; float dt; int velIters, posIters; int defer; /* TOI kernel finishes the step */ int heavyPerWave; int prio; /* rem2d.hip: prio_mode */ };
 
 // Register budget: what the 180-iteration velocity loop touches stays in VGPRs (body velocity,
 // joint effective-mass terms and impulses, KR contact constraints); everything else (pose
@@ -611,6 +611,7 @@ DEV void toi_heavy_body(const State &S, const Terrain &T, const StepArgs &A, uns
     const unsigned sub = threadIdx.x & (G - 1), slot = threadIdx.x / G;
     const unsigned idx = block * per + slot;
     if (slot >= per || idx >= queued) return;
+    if (A.prio & 4) __builtin_amdgcn_s_setprio(3); // (a few hundred wavefronts, each one long dependent chain that the group's next step waits for)
     toi_heavy_one<K>(S, T, A, (unsigned)S.toiWork[16 + idx], ts, (int)sub, (int)G);
 }
 

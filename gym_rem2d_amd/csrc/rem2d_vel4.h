@@ -35,7 +35,7 @@
 #define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
 #define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
-struct Vel4Args { int velIters; float dt; int dbg; /* diagnostic builds (-DREM2D_V4_PROBES) only: 1 skip contact sub-slots, 2 skip joint slots, 8 s_memtime split, 16 start / end time of every wavefront */ };
+struct Vel4Args { int velIters; float dt; int prio, prioT1, prioT2; /* s_setprio for the tiles expected to be slow (rem2d.hip: prio_mode) */ int dbg; /* diagnostic builds (-DREM2D_V4_PROBES) only: 1 skip contact sub-slots, 2 skip joint slots, 8 s_memtime split, 16 start / end time of every wavefront */ };
 #ifdef REM2D_V4_PROBES
 #define V4_DBG(A) ((A).dbg)
 #else
@@ -447,6 +447,16 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
 #pragma unroll
     for (int s = 0; s < V4_PHASES; ++s) subMax[s] = (V4_DBG(A) & 1) ? 0 : wave_max(subMax[s]);
     lds_sync();
+    // A launch lasts as long as its slowest tile, and a tile that shares its SIMD with three other wavefronts runs ~1.5x
+    // slower than alone: the tiles with the most slots per iteration (7 : 10 = cost of a joint slot to a contact sub-slot)
+    // get issue priority on their SIMD.  A scheduling hint only.
+    if (A.prio & 1) {
+        int cost = 7 * P;
+#pragma unroll
+        for (int s = 0; s < V4_PHASES; ++s) cost += 10 * subMax[s];
+        if (cost >= A.prioT2) __builtin_amdgcn_s_setprio(3);
+        else if (cost >= A.prioT1) __builtin_amdgcn_s_setprio(1);
+    }
 
     // ---------------- joint role: one joint per phase and lane ----------------
     JointT J[SETS];
