@@ -285,6 +285,13 @@ DEV void solve_positions_pipelined(const State &S, PosShared &sh, unsigned gl, i
         POS_STAMP(pV)
     }
 #ifdef REM2D_POS_STAMPS
+    if (lane == 0 && 4 * K <= WAVE) { // per block (tools/pos_blocks_probe.py): in the TOI event counters of its first four creatures
+        unsigned env = gl / K;
+        EI(E_TOIEVENTS) = (int)((__builtin_amdgcn_s_memtime() - pT0) >> 6);
+        env += 1; EI(E_TOIEVENTS) = pTicks | (pCsec << 16);
+        env += 1; EI(E_TOIEVENTS) = (int)(pC >> 6);
+        env += 1; EI(E_TOIEVENTS) = (int)(pJ >> 6);
+    }
     if (lane == 0 && pTicks >= 40 * P) { // the wavefronts that iterate to the end only
         const unsigned long long all = __builtin_amdgcn_s_memtime() - pT0;
         atomicAdd(&S.toiWork[2], (int)(pC >> 6)); atomicAdd(&S.toiWork[3], (int)(pJ >> 6)); atomicAdd(&S.toiWork[4], (int)(pV >> 6));
