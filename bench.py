@@ -85,7 +85,7 @@ def pmc_traffic_all():
         except Exception:  # noqa: BLE001
             continue
         ks = {k.split("<")[0].split("(")[0]: float(v["hbm_bytes_per_launch"]) for k, v in d["kernels"].items()
-              if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi"))}
+              if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi"))}
         return {"bytes_per_launch_sequence": sum(ks.values()), "by_kernel": ks, "source": os.path.relpath(path, ROOT)}
     return None
 
@@ -106,7 +106,7 @@ def valu_issue(n_groups):
         if groups != n_groups:
             return None
         per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
-                        if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_post", "rem2d_toi")))
+                        if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi")))
         return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
                 "source": "profiles/%s (per launch of one of the %d step groups of this command), "
                           "profiles/r02_b_ubench_valu_latency.txt" % (name, n_groups)}
@@ -492,6 +492,13 @@ def main():
     n_groups = max(1, len(env.groups))
     kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel",
              1: "rem2d_vel_kernel", 2: "rem2d_vel3_kernel"}[pipeline]
+    fused_velpost = False
+    if pipeline == 3:
+        # (the library's answer: velocity tiles and position iterations of a 64-lane block in ONE launch -- then that launch,
+        # rem2d_velpost_kernel, is the dominant kernel and what the HIP events above timed)
+        _, fused_velpost = env.launch_info()
+        if fused_velpost:
+            kname = "rem2d_velpost_kernel"
     bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
     flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))
     # algorithmic bytes of one launch / its average duration == bytes of all timed launches / their total duration
@@ -542,9 +549,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload_desc, "creatures_total": total, "envs_per_gpu": n_envs,
-                       "pipeline": {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
-                                    1: "split (4-wave velocity kernel)", 2: "split (vel3)"}[pipeline],
-                       "kernel_launches_per_env_step_per_group": (4 if not args.discrete else 3) if pipeline == 3 else None,
+                       "pipeline": ("tile (pre / velpost = vel4 + post + toi_scan / toi_heavy)" if fused_velpost else
+                                    {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
+                                     1: "split (4-wave velocity kernel)", 2: "split (vel3)"}[pipeline]),
+                       "kernel_launches_per_env_step_per_group": ((4 if not args.discrete else 3) - (1 if fused_velpost else 0))
+                       if pipeline == 3 else None,
                        "steps_per_abi_call": spl,
                        "settle_steps": args.settle,
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,

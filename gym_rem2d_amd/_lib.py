@@ -142,6 +142,8 @@ def lib(wide=False):
     L.rem2d_abi_version.restype = C.c_int
     L.rem2d_last_error.restype = C.c_char_p
     L.rem2d_capacity.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rem2d_worlds_launch_info.restype = C.c_int
+    L.rem2d_worlds_launch_info.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rem2d_state_bytes.restype = C.c_size_t
     L.rem2d_state_bytes.argtypes = [C.POINTER(WorldCfg)]
     L.rem2d_padded_envs.restype = C.c_int32
@@ -177,7 +179,7 @@ def lib(wide=False):
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 6:
+    if L.rem2d_abi_version() != 7:
         raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
     if wide:
         _libs[True] = L

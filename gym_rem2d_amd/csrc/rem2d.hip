@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -620,12 +621,13 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
 // REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = the fused
 // rem2d_step_kernel of round 1 (one body per lane for the whole step) -- kept as an independently written second
 // formulation that the parity suite runs against the same oracle.
-// REM2D_FUSE_VELPOST=1: velocity iterations and post in one launch where the tile tables allow it (rem2d_velpost_kernel).
-// Measured +1.0 % on config 3 (47.8 vs 47.4 M: the slowest velocity tile is usually the slowest position block as well, so
-// max(v + p) is hardly less than max v + max p); off by default -- the per-phase launches keep the per-kernel timings and
-// profiles of the rounds comparable.
+// Velocity iterations and post in one launch where the tile tables allow it (rem2d_velpost_kernel); REM2D_FUSE_VELPOST=0:
+// always two launches.  The slowest velocity tile is usually the slowest position block as well, so max(v + p) is only a
+// little less than max v + max p: +1.0 % on config 3 in 100-step blocks (47.8 vs 47.4 M), but +1.7 % on the driver's command
+// (20-step blocks, three pairs: 49.18 -> 50.02 M) -- one launch per step and group less also means one launch less to wait
+// for at the join of every call.
 static bool fuse_velpost() {
-    static const bool on = getenv("REM2D_FUSE_VELPOST") && atoi(getenv("REM2D_FUSE_VELPOST")) == 1;
+    static const bool on = !(getenv("REM2D_FUSE_VELPOST") && atoi(getenv("REM2D_FUSE_VELPOST")) == 0);
     return on;
 }
 // Issue priority (s_setprio) for the wavefronts expected to be the long ones of their launch -- bit 1: the velocity tiles
@@ -803,6 +805,24 @@ static int step_fused(rem2d_world *const *ws, int n_worlds, int n_steps, float d
         }
     }
     HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
+
+extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds, int32_t *tile_shape_out, int32_t *fused_velpost) {
+    if (!ws || n_worlds <= 0 || n_worlds > REM2D_MAX_BATCH) return fail(REM2D_E_INVALID, "launch_info: bad world list");
+    for (int i = 0; i < n_worlds; ++i)
+        if (!ws[i]) return fail(REM2D_E_INVALID, "world is NULL");
+    if (pipeline_mode() != 3) { // the fused step kernel: no tiles
+        if (tile_shape_out) *tile_shape_out = -1;
+        if (fused_velpost) *fused_velpost = 0;
+        return REM2D_OK;
+    }
+    static TilePlan P; // (large: kernel arguments of a whole group)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    tiles_plan(P, ws, n_worlds, 1.0f / 50.0f, 180, 60);
+    if (tile_shape_out) *tile_shape_out = P.launchShape;
+    if (fused_velpost) *fused_velpost = P.velpost ? 1 : 0;
     return REM2D_OK;
 }
 

@@ -292,6 +292,15 @@ class BatchedModular2D:
             return w.view("reward"), w.view("done") != 0
         return self._reward, self._done   # written by the step's own kernels (set_outputs in _upload)
 
+    def launch_info(self):
+        """(tile shape, velocity tiles and position iterations in one launch?) of the first step group -- the library's own
+        answer (rem2d_worlds_launch_info); for tools that name kernels, results never depend on it."""
+        idx = self.groups[0] if self.groups else list(range(len(self.worlds)))
+        arr = (C.c_void_p * len(idx))(*[self.worlds[i][0].h for i in idx])
+        shape, fused = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib(self.wide).rem2d_worlds_launch_info(arr, len(idx), C.byref(shape), C.byref(fused)), self.wide)
+        return shape.value, bool(fused.value)
+
     def _gather(self, name, out):
         if len(self.worlds) == 1 and not self._compacted:
             return self.worlds[0][0].view(name).clone()   # a snapshot, like the multi-world path

@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 6 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
-                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity */
+#define REM2D_ABI_VERSION 7 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+                               4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
+                               7: + rem2d_worlds_launch_info */
 
 enum {
     REM2D_OK = 0,
@@ -130,6 +131,12 @@ int rem2d_abi_version(void);
 const char *rem2d_last_error(void);
 /* REM2D_CONTACT_SLOTS / REM2D_SOLVER_SLOTS of this build (either pointer may be NULL) */
 int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots);
+/* How a step of these worlds (one step group: what rem2d_worlds_step would take) is launched -- for tools that name kernels
+ * (bench.py, profiles); results never depend on it.  tile_shape: 3 / 1 / 0 = 64 / 128 / 256 bodies per tile of the velocity
+ * kernel; fused_velpost: 1 = the velocity tiles and the position iterations of a 64-lane block share one launch
+ * (rem2d_velpost_kernel: pre -> velpost -> toi_heavy), 0 = rem2d_vel4_kernel and rem2d_post_multi_kernel.  Either pointer may
+ * be NULL. */
+int rem2d_worlds_launch_info(rem2d_world *const *worlds, int32_t n_worlds, int32_t *tile_shape, int32_t *fused_velpost);
 
 /* Bytes of device memory the caller must provide for a world of this shape. */
 size_t rem2d_state_bytes(const rem2d_world_cfg *cfg);

@@ -369,6 +369,13 @@ int rem2d_cpu_capacity(int32_t *contact_slots, int32_t *solver_slots) {
     if (solver_slots) *solver_slots = REM2D_SOLVER_SLOTS;
     return REM2D_OK;
 }
+/* (no tiles and no launches on the host: the shape of a GPU launch has no counterpart here) */
+int rem2d_cpu_worlds_launch_info(rem2d_cpu_world *const *worlds, int32_t n_worlds, int32_t *tile_shape, int32_t *fused_velpost) {
+    if (!worlds || n_worlds <= 0) return c_fail(REM2D_E_INVALID, "launch_info: bad world list");
+    if (tile_shape) *tile_shape = -1;
+    if (fused_velpost) *fused_velpost = 0;
+    return REM2D_OK;
+}
 int rem2d_cpu_world_enable_timing(rem2d_cpu_world *w, int32_t on) { (void)on; return w ? REM2D_OK : c_fail(REM2D_E_INVALID, "world is NULL"); }
 int rem2d_cpu_world_kernel_time_ms(rem2d_cpu_world *w, double *total_ms, int64_t *launches) {
     if (total_ms) *total_ms = 0.0;

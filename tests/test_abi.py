@@ -36,7 +36,7 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 6
+    assert L.rem2d_abi_version() == 7
     assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
     # a wide world's arena is laid out for its own slot count
     big = lib.WorldCfg(4096, 8, 0, 0)

@@ -2,6 +2,8 @@
 import copy
 import random
 
+import os
+
 import numpy as np
 import pytest
 
@@ -131,6 +133,9 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
         env.use_graph = graph
         env.reset_specs(specs)
         assert len(env.groups) == n_groups
+        if not any(k in os.environ for k in ("REM2D_TILE_SHAPE", "REM2D_FUSE_VELPOST", "REM2D_PIPELINE", "REM2D_RETILE")):
+            # rem2d_worlds_launch_info: 64-body tiles, velocity tiles + position iterations in one launch
+            assert env.launch_info() == (3, True)
         for n in (1, 24, 25, 25, 25, 25, 25):      # (25 five times: the graph of that length is captured once, replayed four times)
             env.step(n)
         torch.cuda.synchronize()
@@ -142,6 +147,7 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
     g[0].worlds, g[0].n_worlds, g[0].stream = None, 0, None
     assert L.rem2d_groups_step(g, 1, 1, None, 0) == -1 and b"no worlds" in L.rem2d_last_error()
     assert L.rem2d_groups_step(g, _lib.MAX_STEP_GROUPS + 1, 1, None, 0) == -1
+    assert L.rem2d_worlds_launch_info(None, 0, None, None) == -1
 
 
 def test_array_population_fitness_is_order_independent(need_gpu):

@@ -394,15 +394,16 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
 
 
 @pytest.mark.parametrize("variant", [{"REM2D_PIPELINE": "0"}, {"REM2D_TILE_SHAPE": "0"}, {"REM2D_TILE_SHAPE": "1"},
-                                     {"REM2D_FUSE_VELPOST": "1"}, {"REM2D_PRIO": "0", "REM2D_HEAVY_PER_WAVE": "2"}],
-                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "velocity_and_position_in_one_launch",
+                                     {"REM2D_FUSE_VELPOST": "0"}, {"REM2D_PRIO": "0", "REM2D_HEAVY_PER_WAVE": "2"}],
+                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "velocity_and_position_in_two_launches",
                               "no_issue_priority_two_toi_bodies_per_wavefront"])
 def test_other_formulations_match_committed_digests(gpu, variant):
     """The library's switches are read once per process, so every other formulation runs in a child process: the fused
     body-per-lane kernel of round 1 (REM2D_PIPELINE=0) and the wider tile shapes of the velocity kernel (256 / 128
-    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default; so does the
-    launch that runs a block's velocity tiles and its position iterations in one wavefront (rem2d_velpost_kernel), and so
-    does the default formulation without its scheduling hints (issue priority, one TOI body per wavefront)."""
+    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default (which runs a
+    block's velocity tiles and its position iterations in one launch, rem2d_velpost_kernel); so do the two launches
+    rem2d_vel4_kernel + rem2d_post_multi_kernel, and so does the default formulation without its scheduling hints (issue
+    priority, one TOI body per wavefront)."""
     import json
     import os
     import subprocess
