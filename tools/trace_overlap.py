@@ -21,6 +21,11 @@ def main():
                                  r.get("Queue_Id", "?")))
     rows.sort()
     rows = rows[-n_last:]
+    # (the window must not span a pause between two passes of the program: keep what follows the last gap of > 5 ms)
+    for i in range(len(rows) - 1, 0, -1):
+        if rows[i][0] - max(r[1] for r in rows[max(0, i - 16):i]) > 5_000_000:
+            rows = rows[i:]
+            break
     if not rows:
         print("no rem2d kernels in trace")
         return
