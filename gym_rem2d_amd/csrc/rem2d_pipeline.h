@@ -189,7 +189,10 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     }
 }
 
-__global__ __launch_bounds__(WAVE) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
+// (four wavefronts per SIMD: 128 VGPRs with 41 of the 137 it would take spilled to scratch.  The kernel is short and every
+// step of its group waits for it; at three per SIMD its 1 946 wavefronts queue behind the other groups' kernels: +2.0 % on
+// config 3, 49.9 -> 50.9 M)
+__global__ __launch_bounds__(WAVE, 4) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
     BATCH_DISPATCH(pre_body)
