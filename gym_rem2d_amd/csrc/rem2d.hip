@@ -726,7 +726,8 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     const dim3 grid(P.blocks), block(WAVE);
     const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                            hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
-    hipLaunchKernelGGL(rem2d_pre_multi_kernel, grid, block, 0, st, P.B, P.A);
+    if (P.launchShape == 3) hipLaunchKernelGGL(rem2d_pre_multi_kernel<4>, grid, block, 0, st, P.B, P.A);
+    else hipLaunchKernelGGL(rem2d_pre_multi_kernel<3>, grid, block, 0, st, P.B, P.A);
     const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
     if (P.velpost) {
         if (timed) {

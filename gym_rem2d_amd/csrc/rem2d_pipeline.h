@@ -189,10 +189,13 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     }
 }
 
-// (four wavefronts per SIMD: 128 VGPRs with 41 of the 137 it would take spilled to scratch.  The kernel is short and every
-// step of its group waits for it; at three per SIMD its 1 946 wavefronts queue behind the other groups' kernels: +2.0 % on
-// config 3, 49.9 -> 50.9 M)
-__global__ __launch_bounds__(WAVE, 4) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
+// Two register budgets.  WPS = 4: 128 VGPRs with 41 of the 137 it would take spilled to scratch.  The kernel is short and every
+// step of its group waits for it; at three per SIMD the wavefronts of a mixed population's launch queue behind the other
+// groups' kernels: +2.0 % on config 3 (49.9 -> 50.9 M), +0.8 % on config 4.  WPS = 3: no spills -- the uniform small
+// creatures of the 128-lane tile shape (65 536 8-module chains: every body touches the ground, pre is a larger share of a
+// 0.35 ms step) lose 2.2 % with the spills (186.8 -> 182.8 M).  The host picks by tile shape (rem2d.hip: tiles_launch_step).
+template <int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
     BATCH_DISPATCH(pre_body)
