@@ -46,15 +46,14 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     const bool active = shape != SHAPE_NONE;
     const float mB = LF(L_INVM), iB = LF(L_INVI);
     const float px = LF(L_PX), py = LF(L_PY), ang = LF(L_ANG);
-    float vx = LF(L_VX), vy = LF(L_VY), w = LF(L_W);
+    // (the velocities, the joint's accumulated impulses and its limit state are loaded where they are first needed, after
+    // the narrowphase: fewer values alive across it)
     float sleepT = LF(L_SLEEPT);
     int awake = LI(L_AWAKE);
     int cCount = LI(L_CCOUNT);
     const int parent = LI(L_PARENT);
     const bool hasJoint = active && parent >= 0;
     const int pl = base + (parent >= 0 ? parent : 0);
-    float impX = LF(L_JIMPX), impY = LF(L_JIMPY), impZ = LF(L_JIMPZ), motorImp = LF(L_JMOTORIMP);
-    int limitState = LI(L_JLIMIT);
     float motorSpeed = LF(L_JMOTORSPEED);
     const int childLo = group_or<K>((hasJoint && parent < 32) ? (1 << parent) : 0);
     const int childHi = group_or<K>((hasJoint && parent >= 32) ? (1 << (parent - 32)) : 0);
@@ -120,6 +119,9 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
         }
     }
     // =============== b2World::Solve (first part) ===============
+    float vx = LF(L_VX), vy = LF(L_VY), w = LF(L_W);
+    float impX = LF(L_JIMPX), impY = LF(L_JIMPY), impZ = LF(L_JIMPZ), motorImp = LF(L_JMOTORIMP);
+    int limitState = LI(L_JLIMIT);
     const int envAwake = group_or<K>(active && awake ? 1 : 0);
     if (envAwake) {
         if (active && (!awake || sleepResetAlways)) { awake = 1; sleepT = 0.0f; } // island.Add -> SetAwake(true)
@@ -189,11 +191,11 @@ DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned 
     }
 }
 
-// Two register budgets.  WPS = 4: 128 VGPRs with 41 of the 137 it would take spilled to scratch.  The kernel is short and every
-// step of its group waits for it; at three per SIMD the wavefronts of a mixed population's launch queue behind the other
-// groups' kernels: +2.0 % on config 3 (49.9 -> 50.9 M), +0.8 % on config 4.  WPS = 3: no spills -- the uniform small
-// creatures of the 128-lane tile shape (65 536 8-module chains: every body touches the ground, pre is a larger share of a
-// 0.35 ms step) lose 2.2 % with the spills (186.8 -> 182.8 M).  The host picks by tile shape (rem2d.hip: tiles_launch_step).
+// WPS = 4: four wavefronts per SIMD (128 VGPRs, no spills since the velocities and the joint's impulses are loaded after the
+// narrowphase; with them alive across it the kernel took 137).  The kernel is short and every step of its group waits for
+// it; at three per SIMD the wavefronts of a mixed population's launch queue behind the other groups' kernels: +2.0 % on
+// config 3 (49.9 -> 50.9 M), +0.8 % on config 4.  WPS = 3 for the wider tile shapes: the 65 536 8-module chains are 1.4 %
+// faster with it (186.6 vs 184.0 M) -- fewer of its wavefronts at once beside the 3-per-SIMD velocity kernel of that shape.
 template <int WPS>
 __global__ __launch_bounds__(WAVE, WPS) void rem2d_pre_multi_kernel(Batch B, StepArgs A) {
     unsigned block = blockIdx.x;
