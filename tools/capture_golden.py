@@ -182,12 +182,25 @@ def install_box2d_stub():
     sys.modules.update({"Box2D": B, "Box2D.b2": b2})
 
 
+def install_neat_stub():
+    """`NeuralNetwork/NEAT_NN.py` does `import neat` at module level (neat-python: pinned by the reference, absent here).
+    Only the import has to succeed: the network capture below never builds a NEAT genome -- it hands the reference's
+    `NN_enc.create()` a duck-typed `nn_g.getPhenotype().activate(x)` (Network_Encoding.py:100-101,177-178)."""
+    neat = types.ModuleType("neat")
+
+    class DefaultGenome:
+        def __init__(self, key):
+            self.key = key
+    neat.DefaultGenome = DefaultGenome
+    sys.modules["neat"] = neat
+
+
 def alias_case_insensitive():
     """The reference was written on a case-insensitive file system
     (`from Encodings import abstract_encoding`, file Abstract_Encoding.py)."""
     import Encodings
     for fn, low in (("Abstract_Encoding.py", "abstract_encoding"), ("Direct_Encoding.py", "direct_encoding"),
-                    ("LSystem.py", "lsystem")):
+                    ("LSystem.py", "lsystem"), ("Cellular_Encoding.py", "cellular_encoding")):
         name = "Encodings." + low
         spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "Encodings", fn))
         mod = importlib.util.module_from_spec(spec)
@@ -254,6 +267,7 @@ def main():
     install_box2d_stub()
     import matplotlib
     matplotlib.use("Agg")
+    install_neat_stub()
     alias_case_insensitive()
     from Encodings import direct_encoding as de, lsystem as ls
     from gym_rem2D.morph import simple_module, circular_module
@@ -303,6 +317,45 @@ def main():
             json.dump(dict(encoding=enc, cases=cases), f)
         nb = [len(c["layout"]["bodies"]) for c in cases]
         print(enc, "bodies per creature: mean %.2f max %d" % (np.mean(nb), max(nb)))
+
+    # ---- network encoding (BASELINE config 4's input generator): the reference's OWN NN_enc.create / update / iterate /
+    # recursiveNodeGen (Network_Encoding.py:86-139,141-222) grow the tree.  Its genome class needs neat-python, so the
+    # encoder is instantiated without __init__ and given what __init__ would have set (:48-84), with nn_g = this
+    # repository's feed-forward CPPN (weights recorded in the fixture): the network is duck-typed (`activate(input)`),
+    # everything downstream of it -- thresholds, module choice, setMorph, setControl, index / depth caps, node order --
+    # is the reference's code.
+    import copy
+    from Encodings import Network_Encoding as ne
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from gym_rem2d_amd.encodings.network import FeedForwardCPPN
+    cases = []
+    for seed in range(64):
+        random.seed(1000 + seed)
+        ml = module_list()
+        g = object.__new__(ne.NN_enc)
+        g.moduleList = copy.deepcopy(ml)
+        g.outputs, g.inputs = [0] * 10, []
+        g.maxTreeDepth, g.maxModules = 7, 20
+        g.networkType = ne.NETWORK_TYPE.CPPN
+        g.nn_g = FeedForwardCPPN()            # (draws its weights from `random`, like NNEncoding.__init__ does at this point)
+        for mod in g.moduleList:              # Network_Encoding.py:83-84
+            mod.mutate(0.5, 0.5, 0.5)
+        for _ in range(seed % 4):             # mutated genomes too (Network_Encoding.py:142-150)
+            g.mutate(0.4, 0.4, 0.3)
+        depth = 7 if seed % 3 else 4
+        net = dict(w1=[list(map(float, r)) for r in g.nn_g.w1], a1=list(map(int, g.nn_g.a1)),
+                   w2=[list(map(float, r)) for r in g.nn_g.w2])
+        protos = [dict(module=dump_module(m), controller=dump_ctrl(m.controller)) for m in g.moduleList]
+        tree = g.create(depth)
+        env = M.Modular2D()
+        env.seed(4)
+        env.reset(tree=tree, module_list=g.moduleList)
+        cases.append(dict(seed=1000 + seed, mutations=seed % 4, depth=depth, network=net, module_list=protos,
+                          tree=dump_tree(tree), layout=dump_layout(env, n_ctrl_steps=3)))
+    with open(os.path.join(OUT, "layout_network.json"), "w") as f:
+        json.dump(dict(encoding="network", cases=cases), f)
+    nb = [len(c["layout"]["bodies"]) for c in cases]
+    print("network bodies per creature: mean %.2f max %d, nodes max %d" % (np.mean(nb), max(nb), max(len(c["tree"]) for c in cases)))
 
     # ---- hand-built chains (BASELINE config 2 morphology) through the reference code
     import Tree as T
