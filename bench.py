@@ -114,60 +114,70 @@ def valu_issue(n_groups):
 
 
 def build_population(workload, n_envs, first):
-    """Host-side synthetic input, built BEFORE the GPU is initialised (uses a fork pool)."""
+    """Host-side synthetic input, first stage, BEFORE the GPU is initialised and before torch is imported (uses a fork
+    pool): the genomes of the population.  finish_population() turns them into lane-bucket batches."""
     from gym_rem2d_amd import synthetic
-    from gym_rem2d_amd.compiler import Morphology, lanes_for
     if workload == "chain4":
         m = synthetic.chain_population(n_envs, 4, "left")
-        return [m], "%d identical 4-module chain creatures, flat terrain, sinusoidal controller" % n_envs
+        return ("morphs", [m], "%d identical 4-module chain creatures, flat terrain, sinusoidal controller" % n_envs)
     if workload == "chain8":
         m = synthetic.chain_population(n_envs, 8, "left")
-        return [m], "%d identical 8-module chain creatures, flat terrain, sinusoidal controller" % n_envs
-    import multiprocessing as mp
-    import pickle
+        return ("morphs", [m], "%d identical 8-module chain creatures, flat terrain, sinusoidal controller" % n_envs)
     import tempfile
     seeds = np.arange(first, first + n_envs)
-    # The specs are cached on disk: a later run (in particular one under rocprofv3 --pmc, whose preloaded library
-    # has initialised the GPU before python starts -- forking a worker pool from such a process hangs) loads them
-    # instead of forking.
-    cache = os.path.join(tempfile.gettempdir(), "rem2d_bench_%s_%d_%d.pkl" % (workload, n_envs, first))
-    parts = None
+    # Only the genomes (a few dozen numbers per creature, drawn from `random` after random.seed(seed)) are made in Python,
+    # by a small fork pool sized to this rank's share of the host cores; tree growth, create_robot, schedule and SoA packing
+    # are the native compilers' (rem2d_compile_lsystem / rem2d_compile_network: the same words as the Python compiler,
+    # tests/test_bench_host.py).  The genome arrays are cached on disk: a later run (in particular one under rocprofv3
+    # --pmc, whose preloaded library has initialised the GPU before python starts -- forking from such a process hangs)
+    # loads them instead of forking.
+    cppn = workload == "cppn_hardcore"
+    maker = synthetic._cppn_genome_chunk if cppn else synthetic._lsystem_genome_chunk
+    cache = os.path.join(tempfile.gettempdir(), "rem2d_bench_genomes_%s_%d_%d.npz" % (workload, n_envs, first))
+    arrays = None
     if os.path.exists(cache):
         try:
-            with open(cache, "rb") as f:
-                parts = pickle.load(f)
+            with np.load(cache) as z:
+                arrays = {k: z[k] for k in z.files}
         except Exception:  # noqa: BLE001
-            parts = None
-    maker = synthetic.cppn_specs if workload == "cppn_hardcore" else synthetic.lsystem_specs
-    if parts is None:
-        n_proc = max(1, min(8 if n_envs <= 131072 else 32, os.cpu_count() or 1))
-        chunks = np.array_split(seeds, n_proc * 8)
-        if os.environ.get("REM2D_BENCH_NO_FORK"):
-            parts = [maker(c.tolist()) for c in chunks]
-        else:
-            with mp.get_context("fork").Pool(n_proc) as pool:
-                parts = pool.map(maker, [c.tolist() for c in chunks])
+            arrays = None
+    if arrays is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        n_proc = 1 if os.environ.get("REM2D_BENCH_NO_FORK") else max(1, min(8, host_cores()[0] // max(1, local_world)))
+        arrays = synthetic._genome_arrays(maker, seeds, None if cppn else 15, n_proc)
         try:
-            with open(cache + ".tmp%d" % os.getpid(), "wb") as f:
-                pickle.dump(parts, f, protocol=pickle.HIGHEST_PROTOCOL)
-            os.replace(cache + ".tmp%d" % os.getpid(), cache)
+            tmp = cache + ".tmp%d.npz" % os.getpid()
+            np.savez(tmp, **arrays)
+            os.replace(tmp, cache)
         except Exception:  # noqa: BLE001
             pass
-    specs = [s for p in parts for s in p]
-    groups = {}
-    for s in specs:
-        groups.setdefault(lanes_for(s.n_bodies), []).append(s)
-    # creatures of one wave run in lockstep: sort every bucket by (pipeline period, joint rounds, bodies) -- the most
-    # complex first, so that their wavefronts (the long ones) are dispatched first
+    return ("genomes", workload, arrays, n_envs, int(seeds[0]), int(seeds[-1]))
+
+
+def finish_population(prep):
+    """Second stage of build_population, AFTER every fork pool of the run is done (the native compilers load librem2d.so,
+    which imports torch first -- nothing is forked from a process in that state): genome arrays -> lane-bucket batches."""
+    if prep[0] == "morphs":
+        return prep[1], prep[2]
+    _, workload, arrays, n_envs, seed0, seed1 = prep
+    from gym_rem2d_amd import encode, synthetic
+    cppn = workload == "cppn_hardcore"
+    seeds = (seed0, seed1)
     desc = os.environ.get("REM2D_SORT_DESC", "1") != "0"
-    for k in groups:
-        groups[k].sort(key=lambda s: (s.period, max(s.rounds, default=-1), s.n_bodies), reverse=desc)
-    morphs = [Morphology.from_specs(groups[k], k) for k in sorted(groups)]
-    if workload == "cppn_hardcore":
+    # creatures of one wave run in lockstep: every bucket sorted by (pipeline period, joint rounds, bodies) -- the most
+    # complex first, so that their wavefronts (the long ones) are dispatched first
+    if cppn:
+        wide = encode.compile_network_arrays(arrays, 7, 20, 32)
+    else:
+        wide = encode.compile_lsystem_arrays(arrays, 8, 15, 16)
+    batches = synthetic.bucket_batches(wide, descending=desc)
+    morphs = [b for b, _ in batches]
+    lanes = [b.lanes for b in morphs]
+    if cppn:
         return morphs, ("%d network-encoded creatures (synthetic feed-forward CPPN genome, seeds %d..%d), hardcore "
-                        "terrain (pits/stumps/stairs), bucketed by lane count %s" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
+                        "terrain (pits/stumps/stairs), bucketed by lane count %s" % (n_envs, seeds[0], seeds[-1], lanes))
     return morphs, ("%d random L-System creatures (seeds %d..%d, maxModules=15, <=16 bodies), flat terrain, "
-                    "bucketed by lane count %s and sorted by joint rounds" % (n_envs, seeds[0], seeds[-1], sorted(groups)))
+                    "bucketed by lane count %s and sorted by joint rounds" % (n_envs, seeds[0], seeds[-1], lanes))
 
 
 def _repack(m, lanes):
@@ -346,8 +356,9 @@ def main():
     ap.add_argument("--step-groups", type=int, default=None,
                     help="independent parts of the population stepped on separate streams (default: automatic)")
     ap.add_argument("--graph", type=int, default=None, choices=[0, 1], help="replay every step call as a hipGraph (REM2D_GRAPH)")
-    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2, 3],
-                    help="3 = tile pipeline pre / rem2d_vel4_kernel / post (the library's default), 0 = fused rem2d_step_multi_kernel")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 3],
+                    help="3 = tile pipeline pre / velocity tiles / post (the library's default), 0 = fused rem2d_step_multi_kernel "
+                         "(launch option `pipeline` of every world, rem2d_world_set_option)")
     ap.add_argument("--discrete", action="store_true",
                     help="b2World(continuousPhysics=False): skip SolveTOI (the default follows pybox2d: continuous)")
     args = ap.parse_args()
@@ -359,7 +370,7 @@ def main():
     if args.step_groups is not None:
         os.environ["REM2D_STEP_GROUPS"] = str(args.step_groups)
     if args.pipeline is not None:
-        os.environ["REM2D_PIPELINE"] = str(args.pipeline)  # read once by librem2d at the first step
+        os.environ["REM2D_PIPELINE"] = str(args.pipeline)  # gym_rem2d_amd._lib.env_options -> rem2d_world_set_option per world
     if args.graph is not None:
         os.environ["REM2D_GRAPH"] = str(args.graph)
 
@@ -389,14 +400,17 @@ def main():
                          "from reset (Demo1_Random_Individual.py path)" % n_envs)
         args.settle = 0
     else:
-        morphs, workload_desc = build_population("lsystem" if generation else args.workload, n_envs, first)
-    if generation:
-        workload_desc = "one EA generation: whole episodes (evaluate() rule, <= 2500 steps) of " + workload_desc
+        prep = build_population("lsystem" if generation else args.workload, n_envs, first)
     # the secondary workloads' host-side input, also before the GPU is initialised (fork pool)
     secondary_in = {}
     if args.workload == "lsystem" and world == 1 and not args.no_secondary and n_envs == 65536 and not args.discrete:
         for wl in ("chain8", "cppn_hardcore"):
             secondary_in[wl] = build_population(wl, 65536, 0)
+    if not single:
+        morphs, workload_desc = finish_population(prep)
+    secondary_in = {wl: finish_population(p) for wl, p in secondary_in.items()}
+    if generation:
+        workload_desc = "one EA generation: whole episodes (evaluate() rule, <= 2500 steps) of " + workload_desc
 
     import torch
     import torch.distributed as dist
@@ -469,7 +483,7 @@ def main():
     # library on the launch streams (one more block of K steps of the same population, continuing where the timed
     # region stopped).  Every launch covers one step group (all lane buckets of that part of the population in one
     # grid); its time is booked on the group's first world. ----
-    pipeline = int(os.environ.get("REM2D_PIPELINE", "3"))
+    pipeline = env.worlds[0][0].get_option("pipeline")   # (the launch option the library really runs with)
     ms = launches = 0
     ms_step = n_step = 0
     timing_steps = 0
@@ -490,8 +504,7 @@ def main():
             ms, launches, ms_step, n_step = ms + a, launches + b, ms_step + c, n_step + d
     merged = len(env.worlds) > 1 and env.merged_launch
     n_groups = max(1, len(env.groups))
-    kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel",
-             1: "rem2d_vel_kernel", 2: "rem2d_vel3_kernel"}[pipeline]
+    kname = {3: "rem2d_vel4_kernel", 0: "rem2d_step_multi_kernel"}[pipeline]
     fused_velpost = False
     if pipeline == 3:
         # (the library's answer: velocity tiles and position iterations of a 64-lane block in ONE launch -- then that launch,
@@ -550,8 +563,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_desc, "creatures_total": total, "envs_per_gpu": n_envs,
                        "pipeline": ("tile (pre / velpost = vel4 + post + toi_scan / toi_heavy)" if fused_velpost else
-                                    {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels",
-                                     1: "split (4-wave velocity kernel)", 2: "split (vel3)"}[pipeline]),
+                                    {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels"}[pipeline]),
                        "kernel_launches_per_env_step_per_group": ((4 if not args.discrete else 3) - (1 if fused_velpost else 0))
                        if pipeline == 3 else None,
                        "steps_per_abi_call": spl,

@@ -28,6 +28,33 @@ SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
 
+# launch options of a world (include/rem2d.h REM2D_OPT_*, rem2d_world_set_option): no result depends on them
+OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug")
+OPTION_ID = {n: i for i, n in enumerate(OPTIONS)}
+_ENV_OPTIONS = {"REM2D_PIPELINE": "pipeline", "REM2D_FUSE_VELPOST": "fuse_velpost", "REM2D_PRIO": "prio",
+                "REM2D_PRIO_T1": "prio_t1", "REM2D_PRIO_T2": "prio_t2", "REM2D_HEAVY_PER_WAVE": "heavy_per_wave",
+                "REM2D_V4_DBG": "debug"}
+
+
+def env_options():
+    """Experiment overrides for bench.py and tools/: REM2D_PIPELINE, REM2D_FUSE_VELPOST, REM2D_PRIO, REM2D_PRIO_T1 / _T2,
+    REM2D_HEAVY_PER_WAVE, REM2D_V4_DBG from the environment as {option: value} -- what BatchedWorld hands to
+    rem2d_world_set_option for every world it creates.  The LIBRARY reads no environment variable; this is the only place
+    where the variables mean anything."""
+    return {opt: int(os.environ[var]) for var, opt in _ENV_OPTIONS.items() if os.environ.get(var, "") != ""}
+
+
+def env_tile_shape():
+    """REM2D_TILE_SHAPE (0 / 1 / 3) as an experiment override of the tile shape, or None."""
+    v = os.environ.get("REM2D_TILE_SHAPE", "")
+    return int(v) if v != "" else None
+
+
+def env_tile_creatures():
+    """REM2D_TILE_CREATURES: cap on the creatures per velocity tile (rem2d_plan_tiles' max_creatures), 0 = the default."""
+    v = os.environ.get("REM2D_TILE_CREATURES", "")
+    return int(v) if v != "" else 0
+
 # field ids: order of the enum in include/rem2d.h
 FIELDS = [
     "px", "py", "ang", "vx", "vy", "w", "sleept", "hx", "hy", "invm", "invi",
@@ -106,9 +133,12 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    failed = None
+    for cmd, pr in procs:   # (wait for every child before raising: no compile is left running behind an exception)
+        if pr.wait() != 0 and failed is None:
+            failed = (pr.returncode, cmd)
+    if failed is not None:
+        raise subprocess.CalledProcessError(*failed)
     return LIB_PATH
 
 
@@ -159,6 +189,8 @@ def lib(wide=False):
     L.rem2d_plan_tiles_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     L.rem2d_world_set_tile_shape.argtypes = [C.c_void_p, C.c_int32]
+    L.rem2d_world_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.rem2d_world_get_option.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.rem2d_world_adopt.argtypes = [C.c_void_p]
     L.rem2d_world_step.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_step_ex.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
@@ -174,12 +206,13 @@ def lib(wide=False):
     L.rem2d_compile_network.argtypes = [C.POINTER(NetworkGenomes), C.c_int32, C.c_double, C.c_int32, C.POINTER(Morph),
                                         C.c_void_p, C.c_int32]
     L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.rem2d_selftest_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_int32)]
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 7:
+    if L.rem2d_abi_version() != 8:
         raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
     if wide:
         _libs[True] = L
@@ -190,12 +223,15 @@ def lib(wide=False):
 
 def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_shape=-1):
     """Tile plan of the velocity kernel for one morphology batch (rem2d_plan_tiles_shape): int32 tile starts
-    [n_tiles + 1].  tile_shape: 0 / 1 / 3, or -1 for the process default."""
+    [n_tiles + 1].  tile_shape: 0 / 1 / 3, or -1 for the default (3); max_creatures 0: the library's default cap unless
+    REM2D_TILE_CREATURES overrides it (experiments)."""
     import numpy as np
     parent = np.ascontiguousarray(parent, dtype=np.int32)
     jround = np.ascontiguousarray(jround, dtype=np.int32)
     out = np.zeros(int(n_padded) + 1, dtype=np.int32)
     n = C.c_int32()
+    if max_creatures <= 0:
+        max_creatures = env_tile_creatures()
     check(lib().rem2d_plan_tiles_shape(parent.ctypes.data, jround.ctypes.data, int(n_envs), int(lanes), int(n_padded),
                                        int(max_creatures), int(tile_shape), out.ctypes.data, C.byref(n)))
     return out[:n.value + 1].copy()

@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -128,28 +129,36 @@ struct rem2d_world {
     int64_t launchesStep;
     hipEvent_t evFork, evJoin; // fork / join edges of rem2d_groups_step (created on first use)
     uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
+    int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
 };
 
-// Tile shape of rem2d_vel4_kernel (REM2D_TILE_SHAPE, read once per process; rem2d_vel4.h explains the trade-off):
-//   (the process-wide default of a world's shape; rem2d_world_set_tile_shape overrides it per world)
+// Tile shape of rem2d_vel4_kernel (rem2d_world_set_tile_shape; rem2d_vel4.h explains the trade-off):
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
 //   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
 struct TileShape { int sets, passes, csets; };
-// bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel (rem2d_kernels.h); REM2D_HEAVY_PER_WAVE, 1..64.
-// One: a wavefront that holds two runs the union of their code paths (64 -> 8 -> 2 -> 1 bodies: 36.0 -> 37.4 -> 37.9 M in
-// round 2, 47.38 -> 47.55 M for 2 -> 1 now that the sub-step's sweeps are split over a body's lanes).
-static int heavy_per_wave() {
-    static const int n = getenv("REM2D_HEAVY_PER_WAVE") ? atoi(getenv("REM2D_HEAVY_PER_WAVE")) : 1;
-    return n < 1 ? 1 : (n > WAVE ? WAVE : n);
-}
-static int tile_shape_id() {
-    static const int id = getenv("REM2D_TILE_SHAPE") ? atoi(getenv("REM2D_TILE_SHAPE")) : 3;
-    return (id == 0 || id == 1) ? id : 3;
-}
+#define DEFAULT_TILE_SHAPE 3
 static TileShape tile_shape(int id) {
     static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}}; // [2] unused
     return shapes[(id == 0 || id == 1) ? id : 3];
 }
+// Launch options of a world (include/rem2d.h REM2D_OPT_*): defaults and valid ranges.  None of them changes a result; the
+// library reads no environment variable -- hosts that want overrides for experiments pass them here (gym_rem2d_amd._lib
+// maps REM2D_* variables onto these calls for bench.py and the tools).
+//   PIPELINE       3 = tile pipeline pre -> velocity tiles -> post (default), 0 = the fused body-per-lane step kernel of round 1,
+//                  kept as an independently written second formulation that the parity suite runs against the same oracle
+//   FUSE_VELPOST   velocity tiles and position iterations of a 64-lane block in one launch (rem2d_velpost_kernel) where the
+//                  tile tables allow it.  The slowest velocity tile is usually the slowest position block as well, so
+//                  max(v + p) is only a little less than max v + max p: +1.0 % on config 3 in 100-step blocks, +1.7 % on the
+//                  driver's command (one launch per step and group less to wait for at the join of every call)
+//   PRIO           issue priority (s_setprio) for the wavefronts expected to be the long ones of their launch -- bit 1: the
+//                  velocity tiles with the most slots per iteration (cost 7 ticks + 10 sub-slots >= PRIO_T1: priority 1,
+//                  >= PRIO_T2: priority 3), bit 4: the wavefronts of the TOI solve.  profiles/r03_prio.txt: config 3 +4.6 %
+//   HEAVY_PER_WAVE bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel, 1..64 (one: a wavefront that
+//                  holds two runs the union of their code paths)
+//   DEBUG          diagnostic builds (-DREM2D_V4_PROBES) only: Vel4Args::dbg
+static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0};
+static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0};
+static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, WAVE, 1 << 30};
 
 static uint32_t __float_as_uint_host(float f) {
     uint32_t u;
@@ -179,8 +188,8 @@ extern "C" int32_t rem2d_padded_envs(const rem2d_world_cfg *cfg) {
     return make_layout(cfg).Np;
 }
 
-static uint64_t next_epoch() {
-    static uint64_t e = 0;
+static uint64_t next_epoch() { // (worlds of different host threads draw from it)
+    static std::atomic<uint64_t> e{0};
     return ++e;
 }
 static void bind_state(rem2d_world *w) {
@@ -227,6 +236,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->launches = 0;
     w->evFork = w->evJoin = nullptr;
     w->epoch = next_epoch();
+    for (int k = 0; k < REM2D_OPT_COUNT; ++k) w->opt[k] = kOptDefault[k];
     bind_state(w);
     w->S.scr = nullptr;
     hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
@@ -260,7 +270,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
     {
         // (with one joint set per lane a tile holds at most 64 joints: 64 / lanes creatures)
-        w->tileShape = tile_shape_id();
+        w->tileShape = DEFAULT_TILE_SHAPE;
         const TileShape shp = tile_shape(w->tileShape);
         // 4 sets = one phase per set: 128 / lanes creatures; fewer sets share phases, so keep to 64 joints in all
         int per = (shp.sets >= 4 ? 128 : 64) / cfg->lanes;
@@ -317,6 +327,24 @@ extern "C" int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape_sel
     return rem2d_world_set_tiles(w, ts.data(), (int32_t)ts.size() - 1);
 }
 
+extern "C" int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if (key < 0 || key >= REM2D_OPT_COUNT) return fail(REM2D_E_INVALID, "set_option: unknown option");
+    if (value < kOptMin[key] || value > kOptMax[key] || (key == REM2D_OPT_PIPELINE && value != 0 && value != 3))
+        return fail(REM2D_E_INVALID, "set_option: value out of range for this option");
+    if (w->opt[key] != value) {
+        w->opt[key] = value;
+        w->epoch = next_epoch(); // (a captured replay of the old launch sequence is stale)
+    }
+    return REM2D_OK;
+}
+extern "C" int rem2d_world_get_option(const rem2d_world *w, int32_t key, int32_t *value) {
+    if (!w || !value) return fail(REM2D_E_INVALID, "get_option: NULL argument");
+    if (key < 0 || key >= REM2D_OPT_COUNT) return fail(REM2D_E_INVALID, "get_option: unknown option");
+    *value = w->opt[key];
+    return REM2D_OK;
+}
+
 extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_tiles) {
     if (!w || !tile_start || n_tiles <= 0) return fail(REM2D_E_INVALID, "tiles: NULL table or no tiles");
     if (tile_start[0] != 0 || tile_start[n_tiles] < w->cfg.n_envs || tile_start[n_tiles] > w->L.Np)
@@ -360,16 +388,15 @@ extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jrou
                                       int32_t *n_tiles_out) {
     if (!parent || !jround || !tile_start_out || !n_tiles_out) return fail(REM2D_E_INVALID, "plan_tiles: NULL argument");
     if (tile_shape_sel != -1 && tile_shape_sel != 0 && tile_shape_sel != 1 && tile_shape_sel != 3)
-        return fail(REM2D_E_INVALID, "plan_tiles: tile shape must be 0, 1, 3 or -1 (process default)");
-    const TileShape sh = tile_shape(tile_shape_sel < 0 ? tile_shape_id() : tile_shape_sel);
+        return fail(REM2D_E_INVALID, "plan_tiles: tile shape must be 0, 1, 3 or -1 (the default, 3)");
+    const TileShape sh = tile_shape(tile_shape_sel < 0 ? DEFAULT_TILE_SHAPE : tile_shape_sel);
     const int maxLanes = sh.passes * WAVE;
     if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
     if (max_creatures <= 0) {
-        static const int envCap = getenv("REM2D_TILE_CREATURES") ? atoi(getenv("REM2D_TILE_CREATURES")) : 0;
         // (64-lane tiles: two-lane creatures, 32 to a tile, are faster 16 to a tile -- 46.8 vs 46.4 M on config 3, 55 vs 49 M on
         // config 4; the wider shapes are taken where instruction issue limits, and more tiles are more instructions)
-        const int shapeId = tile_shape_sel < 0 ? tile_shape_id() : tile_shape_sel;
-        max_creatures = envCap > 0 ? envCap : (shapeId == 3 ? 16 : 32);
+        const int shapeId = tile_shape_sel < 0 ? DEFAULT_TILE_SHAPE : tile_shape_sel;
+        max_creatures = shapeId == 3 ? 16 : 32;
     }
     const int capBodies = maxLanes / lanes; // creatures per tile by lanes
     const int cap = max_creatures < capBodies ? max_creatures : capBodies;
@@ -618,31 +645,7 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
     return REM2D_OK;
 }
 
-// REM2D_PIPELINE (read once per process): 3 = tile pipeline pre -> rem2d_vel4_kernel -> post (default), 0 = the fused
-// rem2d_step_kernel of round 1 (one body per lane for the whole step) -- kept as an independently written second
-// formulation that the parity suite runs against the same oracle.
-// Velocity iterations and post in one launch where the tile tables allow it (rem2d_velpost_kernel); REM2D_FUSE_VELPOST=0:
-// always two launches.  The slowest velocity tile is usually the slowest position block as well, so max(v + p) is only a
-// little less than max v + max p: +1.0 % on config 3 in 100-step blocks (47.8 vs 47.4 M), but +1.7 % on the driver's command
-// (20-step blocks, three pairs: 49.18 -> 50.02 M) -- one launch per step and group less also means one launch less to wait
-// for at the join of every call.
-static bool fuse_velpost() {
-    static const bool on = !(getenv("REM2D_FUSE_VELPOST") && atoi(getenv("REM2D_FUSE_VELPOST")) == 0);
-    return on;
-}
-// Issue priority (s_setprio) for the wavefronts expected to be the long ones of their launch -- bit 1: the velocity tiles
-// with the most slots per iteration, bit 4: the wavefronts of the TOI solve.  REM2D_PRIO=0 switches it off.  Measured
-// (profiles/r03_prio.txt): config 3 47.4 -> 49.5 M (TOI alone +2.8 %, tiles alone +1.7 %), config 4 +3.3 %, the generation
-// workload +1.4 %, uniform populations unchanged; priority for the long position blocks (most blocks are long) costs 1.5 %,
-// for pre nothing, by measured pace instead of slot count nothing.
-static int prio_mode() {
-    static const int on = getenv("REM2D_PRIO") ? atoi(getenv("REM2D_PRIO")) : 5;
-    return on;
-}
-static int pipeline_mode() {
-    static const int mode = getenv("REM2D_PIPELINE") ? atoi(getenv("REM2D_PIPELINE")) : 3;
-    return mode == 0 ? 0 : 3;
-}
+static int pipeline_mode(const rem2d_world *w) { return w->opt[REM2D_OPT_PIPELINE] == 0 ? 0 : 3; }
 
 // The tile pipeline for one or several worlds (lane buckets) in one grid per kernel: pre and post run one body per
 // lane; the velocity iterations run one tile per wavefront (rem2d_vel4.h).  TilePlan = the launch arguments of one env-step of
@@ -696,7 +699,7 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
         const int id = ws[i]->tileShape;
         if (id == 0 || (id == 1 && P.launchShape == 3)) P.launchShape = id;
     }
-    P.velpost = fuse_velpost() && P.launchShape == 3;
+    P.velpost = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] != 0 && P.launchShape == 3;
     for (int i = 0; i < n_worlds; ++i)
         P.velpost = P.velpost && ws[i]->S.tileCap > 0 && !(ws[i]->cfg.flags & REM2D_FLAG_RETILE) && ws[i]->tileShape == 3;
     P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
@@ -704,17 +707,15 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
     P.A.dt = dt;
     P.A.velIters = vel_iters;
     P.A.posIters = pos_iters;
-    P.A.heavyPerWave = heavy_per_wave();
-    P.A.prio = P.V.prio = prio_mode();
-    static const int t1 = getenv("REM2D_PRIO_T1") ? atoi(getenv("REM2D_PRIO_T1")) : 60;
-    static const int t2 = getenv("REM2D_PRIO_T2") ? atoi(getenv("REM2D_PRIO_T2")) : 75;
-    P.V.prioT1 = t1;
-    P.V.prioT2 = t2;
+    // (the options of the group's first world steer the launch: a group is one launch sequence)
+    P.A.heavyPerWave = ws[0]->opt[REM2D_OPT_HEAVY_PER_WAVE];
+    P.A.prio = P.V.prio = ws[0]->opt[REM2D_OPT_PRIO];
+    P.V.prioT1 = ws[0]->opt[REM2D_OPT_PRIO_T1];
+    P.V.prioT2 = ws[0]->opt[REM2D_OPT_PRIO_T2];
     P.A.defer = P.continuous ? 2 : 0; // 2: post runs the TOI scan itself (the fused kernel's path keeps 1 = separate scan kernel)
     P.V.velIters = vel_iters;
     P.V.dt = dt;
-    static const int v4dbg = getenv("REM2D_V4_DBG") ? atoi(getenv("REM2D_V4_DBG")) : 0;
-    P.V.dbg = v4dbg;
+    P.V.dbg = ws[0]->opt[REM2D_OPT_DEBUG];
 }
 // one env-step of one step group.  With timing on (rem2d_world_enable_timing; never inside a region whose wall time is
 // being measured -- bench.py times kernels in a pass of its own) the dominant kernel gets its own begin / end timestamps
@@ -791,8 +792,8 @@ static int step_fused(rem2d_world *const *ws, int n_worlds, int n_steps, float d
     A.dt = dt;
     A.velIters = vel_iters;
     A.posIters = pos_iters;
-    A.heavyPerWave = heavy_per_wave();
-    A.prio = prio_mode();
+    A.heavyPerWave = w0->opt[REM2D_OPT_HEAVY_PER_WAVE];
+    A.prio = w0->opt[REM2D_OPT_PRIO];
     A.defer = continuous ? 1 : 0;
     dim3 grid(blocks), block(WAVE);
     const int launches = continuous ? n_steps : 1;
@@ -813,7 +814,7 @@ extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds
     if (!ws || n_worlds <= 0 || n_worlds > REM2D_MAX_BATCH) return fail(REM2D_E_INVALID, "launch_info: bad world list");
     for (int i = 0; i < n_worlds; ++i)
         if (!ws[i]) return fail(REM2D_E_INVALID, "world is NULL");
-    if (pipeline_mode() != 3) { // the fused step kernel: no tiles
+    if (pipeline_mode(ws[0]) != 3) { // the fused step kernel: no tiles
         if (tile_shape_out) *tile_shape_out = -1;
         if (fused_velpost) *fused_velpost = 0;
         return REM2D_OK;
@@ -827,19 +828,31 @@ extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds
     return REM2D_OK;
 }
 
+// The solver loops count ticks (iteration x schedule period + joint round) in 16 bits (wave_max_active): refuse iteration
+// counts that would not fit instead of silently running fewer sweeps.  (Box2D's own arguments are 8 / 3; the reference
+// passes 180 / 60, Modular2DEnv.py:634.)
+#define REM2D_MAX_ITERS 8192
+static bool iters_ok(int vel_iters, int pos_iters) {
+    return vel_iters >= 0 && pos_iters >= 0 && vel_iters <= REM2D_MAX_ITERS && pos_iters <= REM2D_MAX_ITERS;
+}
+#define ITERS_TRY(v, p) \
+    do { if (!iters_ok((v), (p))) return fail(REM2D_E_INVALID, "velocity / position iterations must be in 0..8192"); } while (0)
+
 extern "C" int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                                    void *stream) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    ITERS_TRY(vel_iters, pos_iters);
     if (!w->haveTerrain) return fail(REM2D_E_STATE, "rem2d_world_set_terrain must be called before step");
     if (!w->haveReset) return fail(REM2D_E_STATE, "rem2d_world_reset must be called before step");
     if (n_steps <= 0) return REM2D_OK;
     HIP_TRY(hipSetDevice(w->cfg.device));
-    if (pipeline_mode() == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    if (pipeline_mode(w) == 3) return step_tiles(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
     return step_fused(&w, 1, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
 }
 extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                                     int32_t pos_iters, void *stream) {
     if (!ws || n_worlds <= 0) return fail(REM2D_E_INVALID, "no worlds");
+    ITERS_TRY(vel_iters, pos_iters);
     if (n_worlds == 1) return rem2d_world_step_ex(ws[0], n_steps, dt, vel_iters, pos_iters, stream);
     if (n_worlds > REM2D_MAX_WORLDS_PER_STEP) return fail(REM2D_E_INVALID, "too many worlds for one launch");
     static_assert(REM2D_MAX_WORLDS_PER_STEP == REM2D_MAX_BATCH, "batch size");
@@ -855,7 +868,7 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     if (n_steps <= 0) return REM2D_OK;
     rem2d_world *w0 = ws[0];
     HIP_TRY(hipSetDevice(w0->cfg.device));
-    if (pipeline_mode() == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    if (pipeline_mode(w0) == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
     return step_fused(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
 }
 extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, void *stream) {
@@ -877,6 +890,10 @@ struct GraphEntry {
     std::vector<const rem2d_world *> worlds; // whose kernel arguments and fork / join events the replay holds
 };
 static std::vector<GraphEntry> g_graphs;
+// one lock for the replay cache and the capture stream: ctypes releases the GIL around the ABI calls, so two host threads
+// may step / destroy different envs at once.  Held across capture, instantiate and launch (a capture in Relaxed mode on
+// the one shared capture stream must not interleave with another) and while a destroy drops the replays of its world.
+static std::mutex g_graphMu;
 static void graph_entry_free(GraphEntry &e) {
     (void)hipDeviceSynchronize(); // (a replay may still be in flight)
     (void)hipGraphExecDestroy(e.exec);
@@ -884,6 +901,7 @@ static void graph_entry_free(GraphEntry &e) {
 }
 // a world is going away: so must every replay that was captured with it (its events and scratch pointers)
 static void graphs_forget(const rem2d_world *w) {
+    std::lock_guard<std::mutex> lk(g_graphMu);
     for (size_t i = 0; i < g_graphs.size();) {
         bool uses = false;
         for (const rem2d_world *x : g_graphs[i].worlds) uses = uses || x == w;
@@ -946,6 +964,7 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
                                     int32_t vel_iters, int32_t pos_iters, void *stream, uint32_t flags) {
     if (!groups || n_groups <= 0) return fail(REM2D_E_INVALID, "no step groups");
     if (n_groups > REM2D_MAX_STEP_GROUPS) return fail(REM2D_E_INVALID, "too many step groups");
+    ITERS_TRY(vel_iters, pos_iters);
     rem2d_world *w00 = nullptr;
     bool timing = false;
     for (int g = 0; g < n_groups; ++g) {
@@ -970,12 +989,13 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
         if (!wg->evFork) HIP_TRY(hipEventCreateWithFlags(&wg->evFork, hipEventDisableTiming));
         if (!wg->evJoin) HIP_TRY(hipEventCreateWithFlags(&wg->evJoin, hipEventDisableTiming));
     }
-    const bool tiles = pipeline_mode() == 3;
+    const bool tiles = pipeline_mode(w00) == 3;
     hipStream_t origin = (hipStream_t)stream;
     if (!(flags & REM2D_STEP_GRAPH) || timing || !tiles)
         return groups_enqueue(groups, n_groups, n_steps, dt, vel_iters, pos_iters, origin, tiles);
 
     // ---- graph replay ----
+    std::lock_guard<std::mutex> graphLock(g_graphMu);
     uint64_t key = mix64(0x5bd1e995u, (uint64_t)n_steps);
     key = mix64(key, (uint64_t)__float_as_uint_host(dt));
     key = mix64(key, ((uint64_t)(uint32_t)vel_iters << 32) | (uint32_t)pos_iters);
@@ -1042,6 +1062,28 @@ extern "C" int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_
 }
 
 #include "rem2d_compile.h"
+
+// ---- self-test of the scalar helpers the solvers are built from (include/rem2d.h rem2d_selftest_scalar) ----
+__global__ void rem2d_selftest_scalar_kernel(const float *a, const float *b, const float *c, int n, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = fmin32(a[i], b[i]);
+    out[(size_t)n + i] = fmax32(a[i], b[i]);
+    out[2 * (size_t)n + i] = fclamp(a[i], b[i], c[i]);
+    const Rot q = rot_set(a[i]);
+    out[3 * (size_t)n + i] = q.s;
+    out[4 * (size_t)n + i] = q.c;
+}
+extern "C" int rem2d_selftest_scalar(const float *a_dev, const float *b_dev, const float *c_dev, int32_t n, float *out_dev,
+                                     int32_t device, void *stream) {
+    if (!a_dev || !b_dev || !c_dev || !out_dev) return fail(REM2D_E_INVALID, "NULL device pointer");
+    if (n <= 0) return REM2D_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(rem2d_selftest_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a_dev,
+                       b_dev, c_dev, n, out_dev);
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
 
 extern "C" int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
     if (!w || field < 0 || field >= REM2D_F_COUNT) return fail(REM2D_E_INVALID, "bad field id");

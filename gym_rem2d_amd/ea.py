@@ -108,8 +108,13 @@ def run_ea(config=None, population=None, evaluate_batch=None, seed=None, save_di
         env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
 
         def evaluate_batch(inds):
-            return evaluate_population(inds, tree_depth=tree_depth, env=env)
+            # one out-of-domain creature (contacts beyond even the wide build) must not abort a generation: it gets
+            # evaluate.UNRESOLVED_FITNESS, a warning names it, run_ea.last_unresolved keeps the indices per generation
+            fits = evaluate_population(inds, tree_depth=tree_depth, env=env, on_error="penalty")
+            run_ea.last_unresolved.append(list(getattr(env, "last_unresolved", [])))
+            return fits
 
+    run_ea.last_unresolved = []
     if population is None:
         population = [Individual.random(config=config) for _ in range(pop_size)]
         for ind, fit in zip(population, evaluate_batch(population)):

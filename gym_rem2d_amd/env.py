@@ -64,7 +64,9 @@ def group_streams(device, n):
     BatchedModular2D of the process: HIP maps streams onto a few hardware queues and streams that share a queue serialise,
     so a second env must not bring streams of its own (65 536 CPPN creatures: 24.8 M env-steps/s on the 6th-8th stream
     of a process, 45 M on the first three)."""
-    pool = _GROUP_STREAMS.setdefault(str(device), [])
+    dev = torch.device(device if device is not None else "cuda")
+    index = dev.index if dev.index is not None else torch.cuda.current_device()   # (None, "cuda", "cuda:0": ONE pool)
+    pool = _GROUP_STREAMS.setdefault(index, [])
     while len(pool) < n - 1:
         pool.append(torch.cuda.Stream(device=device))
     return [None] + pool[:max(0, n - 1)]
@@ -95,8 +97,8 @@ class BatchedModular2D:
         # REM2D_MERGED_LAUNCH=0: step every lane bucket on its own stream instead of one merged grid
         self.merged_launch = os.environ.get("REM2D_MERGED_LAUNCH", "1") != "0"
         self.step_groups = int(os.environ.get("REM2D_STEP_GROUPS", "0"))  # 0 = automatic
-        # launch shape of the velocity kernel (rem2d_world_set_tile_shape): None = automatic, unless REM2D_TILE_SHAPE
-        # fixes the process default.  Up to ~150 000 creatures a step is bound by its chain of stragglers and the
+        # launch shape of the velocity kernel (rem2d_world_set_tile_shape): None = automatic, unless the experiment
+        # override REM2D_TILE_SHAPE fixes it (_lib.env_tile_shape).  Up to ~150 000 creatures a step is bound by its chain of stragglers and the
         # 64-lane tiles (4 wavefronts per SIMD) win; beyond that the chip's instruction issue saturates and the 256-lane
         # tiles (2.4x fewer wave-instructions) do: 62.1 vs 58.0 M env-steps/s at 196 608 creatures.
         self.tile_shape = None
@@ -183,7 +185,7 @@ class BatchedModular2D:
         # iteration and halves the wavefronts -- 128-lane tiles: 170 M instead of 136 M env-steps/s for 65 536 8-module
         # chains -- once the 64-lane tiles of a step group would no longer fit the chip at once.
         shape = self.tile_shape
-        if shape is None and "REM2D_TILE_SHAPE" not in os.environ:
+        if shape is None and _lib.env_tile_shape() is None:
             shape = 0 if n_envs >= self.BIG_POPULATION else 3
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
                 shape = 1
@@ -255,6 +257,8 @@ class BatchedModular2D:
 
     # ---- step ----
     def step(self, n_steps=1):
+        if not self.groups and len(self.worlds) != 1:   # compact() has retired every world: nothing left to step
+            return self._reward, self._done
         if len(self.worlds) == 1:
             self.worlds[0][0].step(n_steps)
         elif (self.merged_launch and len(self.groups) <= _lib.MAX_STEP_GROUPS

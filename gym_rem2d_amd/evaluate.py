@@ -67,6 +67,15 @@ class SolverOverflow(_lib.Rem2dError):
                          "is not the reference's" % (len(indices), indices[:8], sorted(set(codes))))
 
 
+# What a creature gets whose contacts did not fit even the wide build (run_episode's on_error="penalty"): the value
+# evaluate() starts from and returns for an individual that never scored (REM2D_main.py:361 ``fitness = 0``).  Box2D has
+# no contact cap (Modular2DEnv.py:634), the engine here has two tiers (24 / 6, then 32 / 12 pair / solver slots per body);
+# DESIGN.md 8 shows that no module the reference's classes can produce (boxes <= 1 x 1, circles r <= 0.5: limitWH,
+# simple_module.py:55-68) reaches the second tier's limits, so this is the verdict on hand-built out-of-domain bodies --
+# an EA generation records the mask and goes on instead of raising.
+UNRESOLVED_FITNESS = 0.0
+
+
 def check_errors(env, on_error="raise"):
     """Read the per-creature engine error bits of a BatchedModular2D (REM2D_ERR_PAIR_OVERFLOW / _SOLVER_OVERFLOW).
     on_error: "raise" -> SolverOverflow; "warn" -> warnings.warn and return the mask; "ignore" -> return the mask."""
@@ -139,17 +148,37 @@ def run_episode_masked(env, max_steps=EPISODE_CAP, chunk=100, compact=True, fall
     return fit, bad
 
 
+def apply_penalty(fit, bad, warn=True):
+    """The defined verdict on creatures without a valid fitness (``bad``: bool mask): UNRESOLVED_FITNESS, in place, with a
+    warning that names them.  Returns their indices."""
+    idx = torch.nonzero(torch.as_tensor(bad)).flatten().cpu().tolist()
+    if idx:
+        fit[torch.as_tensor(idx, dtype=torch.long, device=fit.device)] = UNRESOLVED_FITNESS
+        if warn:
+            import warnings
+            warnings.warn("%d creature(s) overflowed even the wide build's contact capacity (first: %s): fitness set to "
+                          "UNRESOLVED_FITNESS = %s" % (len(idx), idx[:8], UNRESOLVED_FITNESS))
+    return idx
+
+
 def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="fallback", compact=True):
     """Advance a BatchedModular2D until every creature's fitness is final (or max_steps).
     Returns fitness[N] (float64 tensor on the env's device).  Engine overflows (see SolverOverflow) are not silent and,
     by default, not fatal: on_error="fallback" re-evaluates the flagged creatures in the wide build (reevaluate_wide) so
     that every individual gets the fitness Box2D would give, and raises only for creatures that overflow even that;
+    on_error="penalty" (what the EA loops use) does the same but never raises: a creature beyond the wide build gets
+    UNRESOLVED_FITNESS, a warning names it and ``env.last_unresolved`` lists it;
     "raise" / "warn" / "ignore" judge the default build's flags without a second attempt.  compact: in worlds created
     with REM2D_FLAG_SKIP_FROZEN (the bodies of finished creatures are nobody's business any more) the survivors are
     moved into smaller worlds between chunks once most of a world has finished (BatchedModular2D.compact) -- same
     fitness, a shorter episode."""
+    if on_error == "penalty":
+        fit, bad = run_episode_masked(env, max_steps, chunk, compact, fallback=True)
+        env.last_unresolved = apply_penalty(fit, bad)
+        return fit
     if on_error == "fallback":
         fit, bad = run_episode_masked(env, max_steps, chunk, compact, fallback=True)
+        env.last_unresolved = torch.nonzero(bad).flatten().cpu().tolist()
         if bool(bad.any()):
             idx = torch.nonzero(bad).flatten().cpu().tolist()
             raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
@@ -164,7 +193,8 @@ def evaluate_population(individuals, tree_depth=None, env=None, max_steps=EPISOD
     """Batched stand-in for ``toolbox.map(toolbox.evaluate, population)``: list of floats.
     The genotype -> phenotype step runs on ``workers`` host processes (encode.encode_population).
     on_error: what to do when a creature overflowed the engine's contact capacity ("fallback": re-evaluate it in the
-    wide build, the default | "raise" | "warn" | "ignore")."""
+    wide build and raise only if even that overflows, the default | "penalty": the same without ever raising, see
+    run_episode | "raise" | "warn" | "ignore")."""
     from .encode import encode_population
     from .env import BatchedModular2D
     own = env is None
@@ -237,11 +267,13 @@ def all_gather_fitness(local, n_total, group=None, flags=None):
     return fit, out[:, 1].reshape(-1)[:n_total] != 0
 
 
-def evaluate_population_sharded(n_total, local_eval, group=None, device=None):
+def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on_error="penalty"):
     """Shard [0, n_total) over the job's ranks, evaluate the local block with
     ``local_eval(lo, hi) -> tensor[hi-lo]`` (or ``-> (tensor, unresolved mask)``, run_episode_masked) and all-gather.
-    Returns fitness[n_total] (float64).  A creature without a valid fitness on ANY rank raises SolverOverflow on EVERY
-    rank, after the collective."""
+    Returns fitness[n_total] (float64).  The mask rides in the same collective, so every rank learns about every rank's
+    unresolved creatures AFTER it: with on_error="penalty" (default) they get UNRESOLVED_FITNESS on every rank alike
+    (``evaluate_population_sharded.last_unresolved`` lists them) and the job goes on; with "raise" every rank raises
+    SolverOverflow in step."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_total, rank, world)
@@ -253,7 +285,10 @@ def evaluate_population_sharded(n_total, local_eval, group=None, device=None):
     if mask is None:
         mask = torch.zeros(local.numel(), dtype=torch.bool, device=local.device)
     fit, bad = all_gather_fitness(local, n_total, group, flags=torch.as_tensor(mask, device=local.device))
+    evaluate_population_sharded.last_unresolved = []
     if bool(bad.any()):
-        idx = torch.nonzero(bad).flatten().cpu().tolist()
-        raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+        if on_error != "penalty":
+            idx = torch.nonzero(bad).flatten().cpu().tolist()
+            raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+        evaluate_population_sharded.last_unresolved = apply_penalty(fit, bad, warn=rank == 0)
     return fit

@@ -201,7 +201,7 @@ def run_generations(pop, n_generations, evaluate, rng, morph_rate=0.01, rate=0.0
     return pop, fit, history
 
 
-def sharded_evaluator(local_eval, group=None, device=None):
+def sharded_evaluator(local_eval, group=None, device=None, on_error="penalty"):
     """evaluate(population) for a torch.distributed job (one process per GPU): every rank holds the whole
     population as arrays (selection and mutation are replicated from a shared seed, so no genome ever crosses a
     rank boundary), expresses and evaluates only its contiguous block ``[lo, hi)`` with
@@ -221,23 +221,30 @@ def sharded_evaluator(local_eval, group=None, device=None):
         local = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
         mask = torch.zeros(local.numel(), dtype=torch.bool) if mask is None else torch.as_tensor(np.asarray(mask))
         # the mask rides in the fitness all-gather: a rank with a creature that has no valid fitness does not raise
-        # before the collective (the others would wait in it for ever) -- every rank raises after it
+        # before the collective (the others would wait in it for ever).  After it every rank holds the same mask: the
+        # creatures get the defined penalty on every rank alike (on_error="penalty": the generation goes on, the indices
+        # are kept in evaluate.last_unresolved) or every rank raises in step (on_error="raise")
         fit, bad = all_gather_fitness(local, len(pop), group, flags=mask.to(local.device))
+        evaluate.last_unresolved = []
         if bool(bad.any()):
-            from .evaluate import SolverOverflow
+            from .evaluate import SolverOverflow, apply_penalty
             from . import _lib
-            idx = torch.nonzero(bad).flatten().cpu().tolist()
-            raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+            if on_error != "penalty":
+                idx = torch.nonzero(bad).flatten().cpu().tolist()
+                raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+            evaluate.last_unresolved = apply_penalty(fit, bad, warn=rank == 0)
         return fit.cpu().numpy().astype(np.float64)
     return evaluate
 
 
-def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False):
+def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False, on_error="penalty"):
     """local_eval for sharded_evaluator / evaluate for run_generations on one GPU: native expression, upload,
     whole episodes (evaluate()'s rule), fitness as float64 numpy.  Creatures that overflow the default build's contact
-    slots are re-evaluated in the wide build (evaluate.reevaluate_wide); one that overflows even that raises
-    SolverOverflow -- or, with masked=True (what a sharded job wants), comes back in a second array
-    ``(fitness, unresolved)`` so that nothing raises before the job's collective."""
+    slots are re-evaluated in the wide build (evaluate.reevaluate_wide); one that overflows even that gets
+    evaluate.UNRESOLVED_FITNESS and is listed in ``evaluate.last_unresolved`` (on_error="penalty", the default: one
+    out-of-domain creature does not abort a generation; "fallback" raises SolverOverflow instead) -- or, with masked=True
+    (what a sharded job wants), comes back in a second array ``(fitness, unresolved)`` so that the verdict is taken after
+    the job's collective."""
     from .env import BatchedModular2D
     from .evaluate import EPISODE_CAP, run_episode, run_episode_masked
     holder = {"env": env}
@@ -253,5 +260,8 @@ def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False):
         if masked:
             fit, bad = run_episode_masked(e, cap)
             return fit.cpu().numpy(), bad.cpu().numpy()
-        return run_episode(e, cap).cpu().numpy()
+        fit = run_episode(e, cap, on_error=on_error).cpu().numpy()
+        evaluate.last_unresolved = list(getattr(e, "last_unresolved", []))
+        return fit
+    evaluate.last_unresolved = []
     return evaluate

@@ -98,3 +98,90 @@ def cppn_specs(seeds):
         spec, _, _ = build_creature(tree.getNodes(), g.moduleList)
         specs.append(spec)
     return specs
+
+
+# ------------------------------------------------------------------------------------------------
+# the same synthetic populations through the native compilers (rem2d_compile_lsystem / rem2d_compile_network): only the
+# genome -- a few dozen numbers drawn from `random` after random.seed(seed), the part that defines "seed k's creature" --
+# is made in Python; tree growth, create_robot, schedule and SoA packing are native (3 us instead of 0.4 ms a creature).
+# tests/test_bench_host.py: the batches equal Morphology.from_specs(lsystem_specs / cppn_specs) word for word.
+# ------------------------------------------------------------------------------------------------
+def _lsystem_genome_chunk(args):
+    seeds, max_modules = args
+    from . import encode
+    gs = []
+    for seed in seeds:
+        random.seed(int(seed))
+        g = LSystem(get_module_list())
+        g.maxModules = max_modules
+        gs.append(g)
+    return encode.lsystem_genome_arrays(gs)
+
+
+def _cppn_genome_chunk(args):
+    seeds, _ = args
+    from . import encode
+    gs = []
+    for seed in seeds:
+        random.seed(int(seed))
+        gs.append(NNEncoding(get_module_list()))
+    return encode.network_genome_arrays(gs)
+
+
+def _genome_arrays(maker, seeds, extra, n_proc):
+    """Genome arrays of `seeds`, made by up to n_proc forked workers (the caller must not have initialised the GPU)."""
+    seeds = np.asarray(list(seeds), dtype=np.int64)
+    if len(seeds) == 0:
+        raise ValueError("no seeds")
+    n_proc = max(1, min(int(n_proc), len(seeds) // 256 or 1))
+    chunks = [c.tolist() for c in np.array_split(seeds, n_proc * 4 if n_proc > 1 else 1) if len(c)]
+    if n_proc > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(n_proc) as pool:
+            parts = pool.map(maker, [(c, extra) for c in chunks])
+    else:
+        parts = [maker((c, extra)) for c in chunks]
+    return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+
+def bucket_batches(m, descending=True):
+    """A compiled batch on wide lanes -> one Morphology per lane count (2, 4, 8, ...), each sorted by (pipeline period,
+    joint rounds, bodies, original index) -- the most complex creatures first by default: their wavefronts are the long
+    ones and should be dispatched first.  Returns [(Morphology, indices into m)]."""
+    K = m.lanes
+    nb = m.n_bodies.astype(np.int64)
+    lanes_of = np.array([lanes_for(int(v)) for v in range(int(nb.max()) + 1)], dtype=np.int64)[nb]
+    jr = m.arrays["jround"].reshape(m.n_envs, K)
+    period = np.maximum(1, (jr >> 16).max(axis=1) & 0xff).astype(np.int64)
+    has_joint = m.arrays["parent"].reshape(m.n_envs, K) >= 0
+    max_round = np.where(has_joint, jr & 0xff, -1).max(axis=1).astype(np.int64)
+    out = []
+    for lanes in sorted(set(lanes_of.tolist())):
+        idx = np.nonzero(lanes_of == lanes)[0]
+        # a stable sort on the key triple, like list.sort(key=(period, max round, bodies), reverse=descending)
+        key = (period[idx] << 32) | ((max_round[idx] + 1) << 16) | nb[idx]
+        order = np.argsort(-key if descending else key, kind="stable")
+        idx = idx[order]
+        b = Morphology(len(idx), lanes)
+        for k, v in m.arrays.items():
+            b.arrays[k][:] = v.reshape(m.n_envs, K)[idx, :lanes].reshape(-1)
+        b.n_bodies[:] = m.n_bodies[idx]
+        out.append((b, idx))
+    return out
+
+
+def lsystem_batches_native(seeds, max_modules=15, n_proc=1, n_threads=0, descending=True):
+    """Config 3's population (one L-system creature per seed, ``lsystem_specs``) as lane buckets, natively compiled."""
+    from . import encode
+    arrays = _genome_arrays(_lsystem_genome_chunk, seeds, max_modules, n_proc)
+    lanes = 64 if max_modules + 1 > 32 else lanes_for(max_modules + 1)
+    m = encode.compile_lsystem_arrays(arrays, 8, max_modules, lanes, n_threads)   # LSystem.treeDepth = 8 (LSystem.py:134-137)
+    return bucket_batches(m, descending)
+
+
+def cppn_batches_native(seeds, n_proc=1, n_threads=0, descending=True):
+    """Config 4's population (one network-encoded creature per seed, ``cppn_specs``) as lane buckets, natively compiled."""
+    from . import encode
+    arrays = _genome_arrays(_cppn_genome_chunk, seeds, None, n_proc)
+    m = encode.compile_network_arrays(arrays, 7, 20, 32, n_threads)   # NNEncoding defaults: depth 7, maxModules 20
+    return bucket_batches(m, descending)

@@ -18,8 +18,10 @@ _DTYPES = {0: torch.float32, 1: torch.int32, 2: torch.float64}
 
 
 class BatchedWorld:
-    def __init__(self, n_envs, lanes, flags=0, device=None, wide=False):
-        """wide: use librem2d_wide.so (32 pair slots / 12 solver slots per body instead of 24 / 6)."""
+    def __init__(self, n_envs, lanes, flags=0, device=None, wide=False, options=None):
+        """wide: use librem2d_wide.so (32 pair slots / 12 solver slots per body instead of 24 / 6).  options: launch options
+        {name: value} (``_lib.OPTIONS``, rem2d_world_set_option) -- launch shapes and scheduling hints, never results;
+        on top of the REM2D_* experiment overrides of the environment (``_lib.env_options``)."""
         if not torch.cuda.is_available():
             raise _lib.Rem2dError("gym_rem2d_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -39,7 +41,23 @@ class BatchedWorld:
         self._views = {}
         self._morph_dev = None
         self.terrain = None
-        self.tile_shape = -1  # -1: the library's process default
+        shape = _lib.env_tile_shape()   # experiment override; None: the library's default (64-lane tiles)
+        self.tile_shape = -1
+        if shape is not None:
+            self._check(L.rem2d_world_set_tile_shape(self.h, shape))
+            self.tile_shape = shape
+        for name, value in dict(_lib.env_options(), **(options or {})).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        """A launch option of this world (``_lib.OPTIONS``: pipeline, fuse_velpost, prio, prio_t1, prio_t2, heavy_per_wave,
+        debug); in a step group the first world's options steer the group's launches."""
+        self._check(self.L.rem2d_world_set_option(self.h, _lib.OPTION_ID[name], int(value)))
+
+    def get_option(self, name):
+        v = C.c_int32()
+        self._check(self.L.rem2d_world_get_option(self.h, _lib.OPTION_ID[name], C.byref(v)))
+        return v.value
 
     def _check(self, rc):
         _lib.check(rc, self.wide)
@@ -78,7 +96,7 @@ class BatchedWorld:
     # ---- reset: upload the morphology and rebuild every world ----
     def reset(self, morph: Morphology, tile_shape=None):
         """tile_shape: launch shape of the velocity kernel for this world (0 / 1 / 3, include/rem2d.h
-        rem2d_world_set_tile_shape); None keeps the world's current one (the process default REM2D_TILE_SHAPE or 3)."""
+        rem2d_world_set_tile_shape); None keeps the world's current one (3 unless REM2D_TILE_SHAPE overrode it)."""
         if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
             raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %
                              (morph.n_envs, morph.lanes, self.n_envs, self.lanes))

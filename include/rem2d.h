@@ -27,9 +27,9 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 7 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+#define REM2D_ABI_VERSION 8 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
-                               7: + rem2d_worlds_launch_info */
+                               7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable) */
 
 enum {
     REM2D_OK = 0,
@@ -196,16 +196,36 @@ int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_env
  * wavefronts per SIMD; faster once the population saturates the chip's instruction issue, from ~160 000 creatures per GPU on).  Replaces the tile table by the default plan of the new shape: call rem2d_world_set_tiles
  * afterwards with a plan made for the same shape (rem2d_plan_tiles_shape).  Results do not depend on it. */
 int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape);
-/* rem2d_plan_tiles for a given tile shape (0, 1, 3; -1 = the process default, REM2D_TILE_SHAPE or 3) */
+/* rem2d_plan_tiles for a given tile shape (0, 1, 3; -1 = the default, 3) */
 int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                            int32_t max_creatures, int32_t tile_shape, int32_t *tile_start_out, int32_t *n_tiles_out);
+
+/* Launch options of a world.  Like the tile shape they are launch shapes / scheduling hints without a counterpart in the
+ * reference (b2World::Step has no such knobs) and NO result depends on them: every combination reproduces the same bits
+ * (tests/test_parity_gpu.py::test_other_formulations_match_committed_digests runs them in one process).  The library reads
+ * no environment variable; a host that wants experiment overrides sets them here (gym_rem2d_amd._lib maps REM2D_* variables
+ * onto these calls for bench.py and tools/).  The options of the FIRST world of a step group steer that group's launches.
+ *   REM2D_OPT_PIPELINE        3 (default): pre -> velocity tiles -> position kernel; 0: the fused body-per-lane step kernel
+ *   REM2D_OPT_FUSE_VELPOST    1 (default): velocity tiles + position iterations of a 64-lane block in one launch; 0: two
+ *   REM2D_OPT_PRIO            s_setprio mask, default 5: bit 1 slow velocity tiles, bit 4 the TOI solve's wavefronts; 0 off
+ *   REM2D_OPT_PRIO_T1 / _T2   slot-cost thresholds (7 per tick + 10 per contact sub-slot) for priority 1 / 3, default 60 / 75
+ *   REM2D_OPT_HEAVY_PER_WAVE  bodies of the TOI work list per wavefront, 1..64, default 1
+ *   REM2D_OPT_DEBUG           diagnostic builds only (-DREM2D_V4_PROBES), default 0
+ * Returns REM2D_E_INVALID for an unknown key or a value outside the option's range. */
+enum {
+    REM2D_OPT_PIPELINE = 0, REM2D_OPT_FUSE_VELPOST, REM2D_OPT_PRIO, REM2D_OPT_PRIO_T1, REM2D_OPT_PRIO_T2,
+    REM2D_OPT_HEAVY_PER_WAVE, REM2D_OPT_DEBUG, REM2D_OPT_COUNT
+};
+int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value);
+int rem2d_world_get_option(const rem2d_world *w, int32_t key, int32_t *value);
 
 /* n_steps x Modular2D.step (Modular2DEnv.py:607-653): wod.update, controller sweep
  * (m_controller.py:17-21), PID -> joint.motorSpeed (:600-605,:631-632),
  * world.Step(1/50, 180, 60) (:634), reward / done (:642-649) and evaluate()'s fitness rule
  * (REM2D_main.py:362-377).  Asynchronous on `stream` (hipStream_t). */
 int rem2d_world_step(rem2d_world *w, int32_t n_steps, void *stream);
-/* same with explicit b2World::Step arguments (dt, velocityIterations, positionIterations) */
+/* same with explicit b2World::Step arguments (dt, velocityIterations, positionIterations); iteration counts outside
+ * 0..8192 are refused with REM2D_E_INVALID (the solver loops count ticks = iterations x schedule period in 16 bits) */
 int rem2d_world_step_ex(rem2d_world *w, int32_t n_steps, float dt, int32_t vel_iters, int32_t pos_iters,
                         void *stream);
 
@@ -309,6 +329,15 @@ int rem2d_compile_network(const rem2d_network_genomes *genomes, int32_t tree_dep
  * asynchronous on `stream`.  Independent of any rem2d_world. */
 int rem2d_tree_diversity(const double *pos_dev, const int32_t *count_dev, int32_t n_trees, int32_t max_nodes,
                          int64_t *out_dev, int32_t device, void *stream);
+
+/* Self-test of the scalar helpers every solver is built from, element by element on the device: out_dev [5][n] =
+ * b2Min(a, b), b2Max(a, b), b2Clamp(a, lo = b, hi = c) (b2Math.h; one v_med3_f32 each here), and b2Rot(a).s / .c (b2Rot::Set;
+ * "rem2d trig").  So that a test can feed the special values no trajectory reaches -- NaN, infinities,
+ * denormals, zeros of either sign -- through the device code and through the oracle's form
+ * (tests/test_parity_gpu.py::test_scalar_helpers_special_values lists where the two may differ: the sign of a zero
+ * result and NaN operands, nothing else).  Device pointers; asynchronous on `stream`.  Independent of any rem2d_world. */
+int rem2d_selftest_scalar(const float *a_dev, const float *b_dev, const float *c_dev, int32_t n, float *out_dev,
+                          int32_t device, void *stream);
 
 /* In-place view of a state field: byte offset into `state`, element count, REM2D_DT_*.
  * Replaces the per-object reads body.position / body.angle / joint.angle and the per-step

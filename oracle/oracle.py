@@ -106,7 +106,9 @@ def _load(path):
             getattr(L, "rem2d_oracle_" + f).argtypes = [C.c_void_p] * (5 if f == "kat_distance" else 6)
         L.rem2d_oracle_kat_toi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.rem2d_oracle_kat_contact_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.rem2d_oracle_kat_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.rem2d_oracle_batch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 5
+        L.rem2d_oracle_batch_run_caps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 5
         L.rem2d_oracle_batch_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_void_p,
                                                 C.c_void_p]
         L.rem2d_oracle_world_from_morph.restype = C.c_void_p
@@ -325,6 +327,14 @@ def batch_toi_stats(reset=True):
     return ev.value, adv.value
 
 
+def kat_scalar(a, b, c):
+    """(b2Min(a, b), b2Max(a, b), b2Clamp(a, b, c)) element-wise in the oracle's own form: float32 [3, n]."""
+    a, b, c = (np.ascontiguousarray(v, dtype=np.float32) for v in (a, b, c))
+    out = np.zeros((3, len(a)), dtype=np.float32)
+    assert lib().rem2d_oracle_kat_scalar(_ptr(a), _ptr(b), _ptr(c), len(a), _ptr(out)) == 0
+    return out
+
+
 def sincosf(a):
     s = C.c_float()
     c = C.c_float()
@@ -367,6 +377,23 @@ def batch_run(terrain, m, n_steps, n_threads=1, flags=0, trace=False):
     if rc != 0:
         raise RuntimeError("rem2d_oracle_batch_run failed: %d" % rc)
     return dict(bodies=bodies, reward=reward, done=done, fitness=fitness, trace=tr)
+
+
+def batch_run_caps(terrain, m, n_steps, n_threads=1, flags=0):
+    """batch_run plus ``caps`` [N, 3]: the most pairs / touching manifolds any body of the creature held while its fitness
+    was still open, and the pairs the oracle itself refused (> O_MAX_BODY_CONTACTS = 32).  Bookkeeping, not arithmetic."""
+    om, keep = make_omorph(m)
+    N, K = om.n_envs, om.lanes
+    bodies = np.zeros((N, K, 8), dtype=np.float32)
+    reward = np.zeros(N, dtype=np.float64)
+    done = np.zeros(N, dtype=np.int32)
+    fitness = np.zeros(N, dtype=np.float64)
+    caps = np.zeros((N, 3), dtype=np.int32)
+    rc = terrain.L.rem2d_oracle_batch_run_caps(terrain.h, C.byref(om), n_steps, n_threads, flags, _ptr(bodies),
+                                           _ptr(reward), _ptr(done), _ptr(fitness), _ptr(caps))
+    if rc != 0:
+        raise RuntimeError("rem2d_oracle_batch_run_caps failed: %d" % rc)
+    return dict(bodies=bodies, reward=reward, done=done, fitness=fitness, caps=caps)
 
 
 def batch_window(terrain, m, settle, window, n_threads=1, flags=0):

@@ -89,6 +89,7 @@ typedef struct rem2d_cpu_world {
     float *outReward;
     uint8_t *outDone;
     const int32_t *outIndex;
+    int32_t opt[REM2D_OPT_COUNT]; /* launch options: stored, never read (no launches on the host) */
 } rem2d_cpu_world;
 
 static _Thread_local char c_err[256];
@@ -120,6 +121,7 @@ int rem2d_cpu_world_create(const rem2d_world_cfg *cfg, void *state_host, size_t 
     w->slotBody = (int8_t *)malloc((size_t)cfg->n_envs * cfg->lanes);
     if (!w->worlds || !w->slotBody) { free(w->worlds); free(w->slotBody); free(w); return c_fail(REM2D_E_NOMEM, "out of memory"); }
     memset(w->arena, 0, L.total);
+    { static const int32_t def[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0}; memcpy(w->opt, def, sizeof def); }
     *out = w;
     return REM2D_OK;
 }
@@ -166,6 +168,22 @@ int rem2d_cpu_world_set_tile_shape(rem2d_cpu_world *w, int32_t tile_shape) {
     if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
     if (tile_shape != 0 && tile_shape != 1 && tile_shape != 3) return c_fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");
     return REM2D_OK; /* a launch shape: nothing to do on the CPU */
+}
+/* launch options (include/rem2d.h REM2D_OPT_*): kept and handed back, nothing to steer on the CPU; same range checks */
+int rem2d_cpu_world_set_option(rem2d_cpu_world *w, int32_t key, int32_t value) {
+    static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30};
+    if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
+    if (key < 0 || key >= REM2D_OPT_COUNT) return c_fail(REM2D_E_INVALID, "set_option: unknown option");
+    if (value < lo[key] || value > hi[key] || (key == REM2D_OPT_PIPELINE && value != 0 && value != 3))
+        return c_fail(REM2D_E_INVALID, "set_option: value out of range for this option");
+    w->opt[key] = value;
+    return REM2D_OK;
+}
+int rem2d_cpu_world_get_option(const rem2d_cpu_world *w, int32_t key, int32_t *value) {
+    if (!w || !value) return c_fail(REM2D_E_INVALID, "get_option: NULL argument");
+    if (key < 0 || key >= REM2D_OPT_COUNT) return c_fail(REM2D_E_INVALID, "get_option: unknown option");
+    *value = w->opt[key];
+    return REM2D_OK;
 }
 int rem2d_cpu_world_field(const rem2d_cpu_world *w, int32_t field, size_t *offset_bytes, size_t *count, int32_t *dtype) {
     if (!w || field < 0 || field >= REM2D_F_COUNT) return c_fail(REM2D_E_INVALID, "bad field id");
@@ -338,6 +356,7 @@ int rem2d_cpu_world_step(rem2d_cpu_world *w, int32_t n_steps, void *stream) {
 int rem2d_cpu_worlds_step_ex(rem2d_cpu_world *const *worlds, int32_t n_worlds, int32_t n_steps, float dt, int32_t vel_iters,
                              int32_t pos_iters, void *stream) {
     if (!worlds || n_worlds <= 0) return c_fail(REM2D_E_INVALID, "no worlds");
+    if (vel_iters < 0 || pos_iters < 0 || vel_iters > 8192 || pos_iters > 8192) return c_fail(REM2D_E_INVALID, "velocity / position iterations must be in 0..8192");
     for (int i = 0; i < n_worlds; ++i) {
         const int rc = rem2d_cpu_world_step_ex(worlds[i], n_steps, dt, vel_iters, pos_iters, stream);
         if (rc != REM2D_OK) return rc;

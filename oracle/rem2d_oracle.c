@@ -511,6 +511,10 @@ struct o_world {
     /* Modular2D state */
     double wod;
     int overflow;
+    /* bookkeeping only (no arithmetic reads them): the most pairs / touching manifolds any body held right after a
+     * Collide or inside a TOI island -- what a fixed-capacity engine (the HIP builds: 24 / 6 and 32 / 12 slots per body)
+     * would have needed; tests that exercise the overflow tiers ask for them (rem2d_oracle_batch_run_caps) */
+    int maxBodyPairs, maxBodyTouching;
 };
 
 static void body_set_awake(o_world *w, body_t *b, int flag) {
@@ -2111,6 +2115,13 @@ void rem2d_oracle_world_step(o_world *w, float dt, int velIters, int posIters) {
     step.dtRatio = w->inv_dt0 * dt;
     step.warmStarting = 1;
     collide(w);
+    for (int i = 0; i < w->nbody; ++i) { /* (bookkeeping: capacity high-water marks) */
+        const body_t *b = &w->bodies[i];
+        int touching = 0;
+        for (int k = 0; k < b->ncontacts; ++k) touching += w->contacts[b->contacts[k]].touching != 0;
+        if (b->ncontacts > w->maxBodyPairs) w->maxBodyPairs = b->ncontacts;
+        if (touching > w->maxBodyTouching) w->maxBodyTouching = touching;
+    }
     if (w->stepComplete && step.dt > 0.0f) world_solve(w, &step);
     if ((w->flags & O_FLAG_CONTINUOUS) && step.dt > 0.0f) world_solve_toi(w, &step);
     if (step.dt > 0.0f) w->inv_dt0 = step.inv_dt;
@@ -3166,6 +3177,17 @@ int rem2d_oracle_kat_contact_solve(const float *in, float *out) {
     out[7] = (float)vc->pointCount;
     return 0;
 }
+/* b2Min / b2Max / b2Clamp as the step uses them (fmin32 / fmax32 / fclamp above), element by element: out = [3][n]
+ * (min(a, b), max(a, b), clamp(a, lo = b, hi = c)).  The checker of the HIP library's rem2d_selftest_scalar, which
+ * evaluates the same three through v_med3_f32 (tests/test_parity_gpu.py::test_scalar_helpers_special_values). */
+int rem2d_oracle_kat_scalar(const float *a, const float *b, const float *c, int32_t n, float *out) {
+    for (int32_t i = 0; i < n; ++i) {
+        out[i] = (float)fmin32((f32)a[i], (f32)b[i]);
+        out[(size_t)n + i] = (float)fmax32((f32)a[i], (f32)b[i]);
+        out[2 * (size_t)n + i] = (float)fclamp((f32)a[i], (f32)b[i], (f32)c[i]);
+    }
+    return 0;
+}
 
 /* ---- batch driver ---- */
 static long long g_batchToiEvents, g_batchToiDynamicAdvances; /* summed over the worlds of rem2d_oracle_batch_run */
@@ -3196,9 +3218,24 @@ o_world *rem2d_oracle_world_from_morph(const o_terrain *t, const o_morph *m, int
     return w;
 }
 
+static int batch_run_impl(const o_terrain *t, const o_morph *m, int n_steps, int n_threads, unsigned flags,
+                          float *bodies_out, double *reward_out, int32_t *done_out, double *fitness_out,
+                          float *trace_out, int32_t *caps_out);
 int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, int n_threads, unsigned flags,
                            float *bodies_out, double *reward_out, int32_t *done_out, double *fitness_out,
                            float *trace_out) {
+    return batch_run_impl(t, m, n_steps, n_threads, flags, bodies_out, reward_out, done_out, fitness_out, trace_out, NULL);
+}
+/* the same, plus caps_out [N][3]: most pairs on one body, most touching manifolds on one body (both sampled while
+ * evaluate()'s loop would still be running for that creature, REM2D_main.py:362-377), refused pairs (> O_MAX_BODY_CONTACTS) */
+int rem2d_oracle_batch_run_caps(const o_terrain *t, const o_morph *m, int n_steps, int n_threads, unsigned flags,
+                                float *bodies_out, double *reward_out, int32_t *done_out, double *fitness_out,
+                                int32_t *caps_out) {
+    return batch_run_impl(t, m, n_steps, n_threads, flags, bodies_out, reward_out, done_out, fitness_out, NULL, caps_out);
+}
+static int batch_run_impl(const o_terrain *t, const o_morph *m, int n_steps, int n_threads, unsigned flags,
+                          float *bodies_out, double *reward_out, int32_t *done_out, double *fitness_out,
+                          float *trace_out, int32_t *caps_out) {
     int N = m->n_envs, K = m->lanes;
     if (K > O_MAX_BODIES) return -1;
     (void)n_threads;
@@ -3213,9 +3250,11 @@ int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, in
         int slotBody[O_MAX_BODIES], nb = 0;
         for (int s = 0; s < K; ++s) slotBody[s] = (m->shape[e * K + s] != 0) ? nb++ : -1;
         float st[O_MAX_BODIES * 8];
+        int capPairs = 0, capTouch = 0;
         for (int step = 0; step < n_steps; ++step) {
             rem2d_oracle_env_step(w, &reward, &done);
             everDone |= done;
+            if (!fitnessFrozen) { capPairs = w->maxBodyPairs; capTouch = w->maxBodyTouching; }
             /* evaluate() (REM2D_main.py:362-377) with EVALUATION_STEPS = 10000, ENV_LENGTH = 100 */
             if (!fitnessFrozen) {
                 if (reward < -10.0) fitnessFrozen = 1;
@@ -3246,6 +3285,7 @@ int rem2d_oracle_batch_run(const o_terrain *t, const o_morph *m, int n_steps, in
         if (reward_out) reward_out[e] = reward;
         if (done_out) done_out[e] = everDone;
         if (fitness_out) fitness_out[e] = fitness;
+        if (caps_out) { caps_out[3 * e] = capPairs; caps_out[3 * e + 1] = capTouch; caps_out[3 * e + 2] = w->overflow; }
         __atomic_fetch_add(&g_batchToiEvents, (long long)w->toiEvents, __ATOMIC_RELAXED);
         __atomic_fetch_add(&g_batchToiDynamicAdvances, (long long)w->toiDynamicAdvances, __ATOMIC_RELAXED);
         rem2d_oracle_world_destroy(w);

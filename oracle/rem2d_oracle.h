@@ -100,6 +100,7 @@ int rem2d_oracle_toi_dynamic_advances(const o_world *);
 
 /* standalone pieces for known-answer tests */
 void rem2d_oracle_sincosf(float a, float *s, float *c);
+int rem2d_oracle_kat_scalar(const float *a, const float *b, const float *c, int32_t n, float *out);
 double rem2d_oracle_sin(double x);
 void rem2d_oracle_box_mass(float hx, float hy, float *mass, float *I);
 void rem2d_oracle_circle_mass(float r, float *mass, float *I);
@@ -115,6 +116,9 @@ void rem2d_oracle_circle_mass(float r, float *mass, float *I);
 int rem2d_oracle_batch_run(const o_terrain *, const o_morph *, int n_steps, int n_threads,
                            unsigned flags, float *bodies_out, double *reward_out,
                            int32_t *done_out, double *fitness_out, float *trace_out);
+int rem2d_oracle_batch_run_caps(const o_terrain *, const o_morph *, int n_steps, int n_threads, unsigned flags,
+                                float *bodies_out, double *reward_out, int32_t *done_out, double *fitness_out,
+                                int32_t *caps_out /* [N][3]: max pairs / max touching manifolds on one body, refused pairs */);
 
 /* bench.py's cpu_baseline leg: `settle` untimed steps of every creature (worlds kept), then ONE continuous wall-clock window
  * around `window` further steps of all of them (OpenMP over creatures).  *seconds_out = the window's wall time. */

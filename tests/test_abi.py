@@ -36,7 +36,7 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 7
+    assert L.rem2d_abi_version() == 8
     assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
     # a wide world's arena is laid out for its own slot count
     big = lib.WorldCfg(4096, 8, 0, 0)
@@ -54,6 +54,23 @@ def test_host_only_entry_points(lib):
     assert L.rem2d_world_destroy(None) == 0
     assert L.rem2d_world_step(None, 1, None) == -1
     assert L.rem2d_groups_step(None, 0, 1, None, 0) == -1 and b"step groups" in L.rem2d_last_error()
+    assert L.rem2d_world_set_option(None, 0, 3) == -1 and L.rem2d_world_get_option(None, 0, None) == -1
+    # iteration counts the 16-bit tick counters of the solver loops cannot hold are refused, not truncated
+    fake = C.c_void_p(8)   # (never dereferenced: the argument check comes first)
+    assert L.rem2d_world_step_ex(fake, 1, 0.02, 70000, 60, None) == -1 and b"0..8192" in L.rem2d_last_error()
+    assert L.rem2d_world_step_ex(fake, 1, 0.02, 180, -1, None) == -1
+
+
+def test_library_reads_no_environment_variable():
+    """The library's launch options are rem2d_world_set_option arguments (include/rem2d.h REM2D_OPT_*): the HIP sources
+    must not call getenv, and the REM2D_* experiment overrides live in gym_rem2d_amd/_lib.py alone."""
+    csrc = os.path.join(ROOT, "gym_rem2d_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    hdr = open(os.path.join(ROOT, "include", "rem2d.h")).read()
+    ids = re.findall(r"\bREM2D_OPT_([A-Z0-9_]+)\b", hdr[hdr.index("REM2D_OPT_PIPELINE = 0"):hdr.index("REM2D_OPT_COUNT")])
+    from gym_rem2d_amd import _lib
+    assert [i.lower() for i in ids] == list(_lib.OPTIONS)
 
 
 def test_product_never_imports_oracle():

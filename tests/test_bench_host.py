@@ -86,3 +86,31 @@ def test_timed_blocks_protocol():
     cores, quota = bench.host_cores()
     assert 1 <= cores <= (os.cpu_count() or 1) and (quota is None or quota > 0)
     assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+
+
+def test_bench_population_is_the_seeded_python_population(tmp_path, monkeypatch):
+    """bench.py builds its populations with the native compilers (genomes by seed in Python, everything after natively):
+    the lane buckets must be, word for word and in the same order, what Morphology.from_specs gives for
+    synthetic.lsystem_specs / cppn_specs of the same seeds sorted the way BatchedModular2D.reset_specs sorts them."""
+    import tempfile
+    import bench
+    from gym_rem2d_amd import synthetic
+    from gym_rem2d_amd.compiler import Morphology, lanes_for
+    monkeypatch.setattr(tempfile, "gettempdir", lambda: str(tmp_path))     # (no stale genome cache, none left behind)
+    monkeypatch.setenv("REM2D_BENCH_NO_FORK", "1")
+    for workload, specs_fn, first, n in (("lsystem", synthetic.lsystem_specs, 4000, 700), ("cppn_hardcore", synthetic.cppn_specs, 50, 300)):
+        for _ in range(2):                                                 # second pass: from the on-disk genome cache
+            morphs, desc = bench.finish_population(bench.build_population(workload, n, first))
+            specs = specs_fn(range(first, first + n))
+            groups = {}
+            for sp in specs:
+                groups.setdefault(lanes_for(sp.n_bodies), []).append(sp)
+            assert [m.lanes for m in morphs] == sorted(groups)
+            for m in morphs:
+                g = sorted(groups[m.lanes], key=lambda sp: (sp.period, max(sp.rounds, default=-1), sp.n_bodies), reverse=True)
+                ref = Morphology.from_specs(g, m.lanes)
+                assert np.array_equal(ref.n_bodies, m.n_bodies)
+                for k in ref.arrays:
+                    assert np.array_equal(ref.arrays[k], m.arrays[k]), (workload, m.lanes, k)
+            assert "seeds %d..%d" % (first, first + n - 1) in desc
+    assert sorted(os.listdir(tmp_path)) == ["rem2d_bench_genomes_cppn_hardcore_300_50.npz", "rem2d_bench_genomes_lsystem_700_4000.npz"]

@@ -453,3 +453,38 @@ def test_render_rgb_array(need_gpu):
     with pytest.raises(NotImplementedError):
         env.render(mode="human")
     env.close()
+
+
+def test_bench_population_exactly_as_benched_equals_the_oracle(need_gpu, oracle, monkeypatch, tmp_path):
+    """The EXACT population bench.py's default line is quoted on -- config 3: 65 536 L-system creatures, seeds 0..65535,
+    built by bench.build_population, uploaded by bench.make_env (four lane buckets x four step groups, merged launches,
+    continuous physics), stepped like the bench steps it (settle 60 + 60 steps, 25 per ABI call) -- with a 2 % sample of
+    every world re-run by the oracle from reset: every pose, velocity, sleep timer and awake flag identical, no error bit
+    anywhere in the population, no NaN."""
+    import tempfile
+    import torch
+    import bench
+    from gym_rem2d_amd import _lib, make_terrain
+    monkeypatch.setattr(tempfile, "gettempdir", lambda: str(tmp_path))
+    monkeypatch.setenv("REM2D_BENCH_NO_FORK", "1")            # (this process has initialised the GPU: no fork pool)
+    morphs, desc = bench.finish_population(bench.build_population("lsystem", 65536, 0))
+    assert "65536 random L-System creatures (seeds 0..65535" in desc and [m.lanes for m in morphs] == [2, 4, 8, 16]
+    dev = torch.device("cuda", 0)
+    env = bench.make_env(morphs, dev, False, True, False)
+    assert len(env.groups) == 4 and len(env.worlds) == 16 and env.launch_info() == (3, True)
+    T = 120
+    bench.stepper(env, 25)(T)
+    torch.cuda.synchronize()
+    assert int(env.errors().max()) == 0
+    ot = oracle_terrain(oracle, make_terrain(4, flat=True))
+    checked = 0
+    for (w, _), part in zip(env.worlds, env._world_morph):
+        got = w.bodies()
+        assert np.isfinite(got).all()
+        pick = np.arange(0, part.n_envs, 50)
+        ref = oracle.batch_run(ot, part.take(pick).as_dict(), T, n_threads=16, flags=oracle.FLAG_CONTINUOUS)
+        assert np.array_equal(got[pick], ref["bodies"]), "world of %d-lane creatures differs from the oracle" % w.lanes
+        assert np.array_equal(w.view("fitness").cpu().numpy()[pick], ref["fitness"])
+        checked += len(pick)
+    assert checked >= 0.02 * 65536
+    env.close()

@@ -393,42 +393,120 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
     assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
 
 
-@pytest.mark.parametrize("variant", [{"REM2D_PIPELINE": "0"}, {"REM2D_TILE_SHAPE": "0"}, {"REM2D_TILE_SHAPE": "1"},
-                                     {"REM2D_FUSE_VELPOST": "0"}, {"REM2D_PRIO": "0", "REM2D_HEAVY_PER_WAVE": "2"}],
+@pytest.mark.parametrize("variant", [{"pipeline": 0}, {"tile_shape": 0}, {"tile_shape": 1}, {"fuse_velpost": 0},
+                                     {"prio": 0, "heavy_per_wave": 2}],
                          ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "velocity_and_position_in_two_launches",
                               "no_issue_priority_two_toi_bodies_per_wavefront"])
 def test_other_formulations_match_committed_digests(gpu, variant):
-    """The library's switches are read once per process, so every other formulation runs in a child process: the fused
-    body-per-lane kernel of round 1 (REM2D_PIPELINE=0) and the wider tile shapes of the velocity kernel (256 / 128
-    bodies per wavefront, 4 / 2 joint register sets) reproduce the same committed digests as the default (which runs a
-    block's velocity tiles and its position iterations in one launch, rem2d_velpost_kernel); so do the two launches
-    rem2d_vel4_kernel + rem2d_post_multi_kernel, and so does the default formulation without its scheduling hints (issue
-    priority, one TOI body per wavefront)."""
+    """The library's switches are per-world launch options (rem2d_world_set_option / rem2d_world_set_tile_shape; it reads no
+    environment variable), so every other formulation runs in this very process: the fused body-per-lane kernel of round 1
+    (pipeline 0) and the wider tile shapes of the velocity kernel (256 / 128 bodies per wavefront, 4 / 2 joint register
+    sets) reproduce the same committed digests as the default (which runs a block's velocity tiles and its position
+    iterations in one launch, rem2d_velpost_kernel); so do the two launches rem2d_vel4_kernel + rem2d_post_multi_kernel, and
+    so does the default formulation without its scheduling hints (issue priority, one TOI body per wavefront)."""
     import json
     import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import make_trajectory_digest as D\n"
-        "from gym_rem2d_amd.world import BatchedWorld\n"
-        "out = {}\n"
-        "for name, pop, ter, flags, steps in D.CASES:\n"
-        "    m, t = D.population(pop), D.terrain(ter)\n"
-        "    w = BatchedWorld(m.n_envs, m.lanes, flags); w.set_terrain(t); w.reset(m); w.step(steps)\n"
-        "    out[name] = D.digest(w.bodies(), m.n_bodies, w.view('reward').cpu().numpy(), w.view('everdone').cpu().numpy(),\n"
-        "                         w.view('fitness').cpu().numpy())\n"
-        "    w.close()\n"
-        "print('DIGESTS ' + json.dumps(out))\n") % (root, os.path.join(root, "tools"))
-    env = dict(os.environ, **variant)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
-    got = json.loads(line[len("DIGESTS "):])
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_trajectory_digest as D
+    variant = dict(variant)
+    shape = variant.pop("tile_shape", None)
+    got = {}
+    for name, pop, ter, flags, steps in D.CASES:
+        m, t = D.population(pop), D.terrain(ter)
+        w = gpu(m.n_envs, m.lanes, flags, options=variant)
+        assert all(w.get_option(k) == v for k, v in variant.items())
+        w.set_terrain(t)
+        w.reset(m, tile_shape=shape)
+        w.step(steps)
+        got[name] = D.digest(w.bodies(), m.n_bodies, w.view('reward').cpu().numpy(), w.view('everdone').cpu().numpy(),
+                             w.view('fitness').cpu().numpy())
+        assert int(w.view("err").max()) == 0
+        w.close()
     with open(os.path.join(root, "tests", "golden", "trajectory_digest.json")) as f:
         gold = json.load(f)["cases"]
     assert got == {k: v["sha256"] for k, v in gold.items()}
+
+
+def test_option_argument_errors(gpu):
+    import ctypes as C
+    from gym_rem2d_amd import _lib
+    w = gpu(4, 4, 0)
+    L = _lib.lib()
+    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 1, 5, 60, 75, 1, 0]     # the documented defaults
+    for key, bad in ((0, 1), (0, 2), (1, 2), (5, 0), (5, 65), (2, -1), (99, 0), (-1, 0)):
+        assert L.rem2d_world_set_option(w.h, key, bad) == -1, (key, bad)
+    assert b"option" in L.rem2d_last_error()
+    assert L.rem2d_world_get_option(w.h, 99, C.byref(C.c_int32())) == -1
+    w.set_option("heavy_per_wave", 64)
+    assert w.get_option("heavy_per_wave") == 64
+    w.close()
+
+
+def test_scalar_helpers_special_values(gpu, oracle):
+    """b2Min / b2Max / b2Clamp are one v_med3_f32 each on the GPU (rem2d_math.h) and ``a < b ? a : b`` chains in the oracle
+    (Box2D's own form).  For every pair / triple of ordinary numbers the two give the same bits; this test feeds both sides
+    the values no trajectory reaches -- NaN, +-inf, denormals, +-0, +-FLT_MAX -- through rem2d_selftest_scalar and
+    rem2d_oracle_kat_scalar and pins down WHERE they may differ, and nowhere else:
+      (1) a result that is a zero may carry the other sign (the median keeps the argument's -0 where Box2D's form hands
+          out a bound's +0; -0 == +0 in every comparison downstream and the trajectory digests canonicalise it);
+      (2) an operand that is NaN (Box2D's form returns whichever operand the failed comparison selects, the median
+          returns a number) -- a state that holds a NaN has left the specification anyway, and every parity test compares
+          with array_equal, which fails on NaN.
+    Denormals are kept on both sides (no flush to zero), infinities clamp like numbers.  The same call checks b2Rot::Set
+    ("rem2d trig") of the device against the oracle's on 200 000 angles incl. huge and denormal ones, bit for bit."""
+    import ctypes as C
+    import torch
+    from gym_rem2d_amd import _lib
+    tiny = np.float32(1e-45)
+    S = np.array([0.0, -0.0, tiny, -tiny, 1e-40, -1e-40, np.finfo(np.float32).tiny, -np.finfo(np.float32).tiny, 1.0, -1.0,
+                  0.5, -2.5, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan], dtype=np.float32)
+    rng = np.random.default_rng(5)
+    a, b, c = [v.ravel() for v in np.meshgrid(S, S, S, indexing="ij")]
+    ok3 = ~(np.isnan(b) | np.isnan(c)) & (b <= c)                # clamp is only ever called with lo <= hi
+    a, b, c = a[ok3], b[ok3], c[ok3]
+    ra = (rng.standard_normal(20000) * 10 ** rng.uniform(-6, 6, 20000)).astype(np.float32)
+    rb = (rng.standard_normal(20000) * 10 ** rng.uniform(-6, 6, 20000)).astype(np.float32)
+    rc = np.maximum(rb, (rng.standard_normal(20000) * 10 ** rng.uniform(-6, 6, 20000)).astype(np.float32))
+    a, b, c = np.concatenate([a, ra]), np.concatenate([b, rb]), np.concatenate([c, rc])
+    n = len(a)
+    dev = torch.device("cuda", 0)
+    ta, tb, tc = (torch.from_numpy(v).to(dev) for v in (a, b, c))
+    out = torch.zeros(5 * n, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().rem2d_selftest_scalar(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), n, out.data_ptr(), 0,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(5, n)
+    ref = oracle.kat_scalar(a, b, c)
+    bits = lambda x: x.view(np.uint32)
+    nan_in = [np.isnan(a) | np.isnan(b), np.isnan(a) | np.isnan(b), np.isnan(a)]
+    report = {}
+    for row, name in enumerate(("min", "max", "clamp")):
+        g, r = got[row], ref[row]
+        same = bits(g) == bits(r)
+        zero_sign = ~same & (g == 0) & (r == 0)                              # (1)
+        nan_case = ~same & nan_in[row]                                       # (2)
+        assert (same | zero_sign | nan_case).all(), (name, a[~(same | zero_sign | nan_case)][:5], b[~(same | zero_sign | nan_case)][:5])
+        assert not np.isnan(g[~nan_in[row]]).any()
+        report[name] = (int(zero_sign.sum()), int(nan_case.sum()))
+        # ordinary numbers, denormals and infinities: identical bits, always
+        plain = ~nan_in[row] & ~((g == 0) & (r == 0))
+        assert (bits(g)[plain] == bits(r)[plain]).all()
+    assert got[0][(a == tiny) & (b == 1.0)][0] == tiny and got[2][(a == -tiny) & (b == -1.0) & (c == 1.0)][0] == -tiny   # no flush
+    print("accepted differences (zero sign, NaN operand):", report)
+    # b2Rot::Set on the device vs the oracle: bit for bit, incl. huge / denormal angles (NaN / inf excluded: rint of them)
+    ang = np.concatenate([rng.uniform(-1e3, 1e3, 150000), rng.uniform(-8, 8, 49000), [0.0, -0.0, 1e-45, -1e-40, 1e6, -3e7] + [0.0] * 994]
+                         ).astype(np.float32)
+    m = len(ang)
+    tang = torch.from_numpy(ang).to(dev)
+    out2 = torch.zeros(5 * m, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().rem2d_selftest_scalar(tang.data_ptr(), tang.data_ptr(), tang.data_ptr(), m, out2.data_ptr(), 0,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize()
+    g2 = out2.cpu().numpy().reshape(5, m)
+    sc = np.array([oracle.sincosf(float(x)) for x in ang[::7]], dtype=np.float32)
+    assert np.array_equal(bits(g2[3][::7].copy()), bits(sc[:, 0].copy())) and np.array_equal(bits(g2[4][::7].copy()), bits(sc[:, 1].copy()))
 
 
 def test_worlds_step_argument_errors(gpu, flat_terrain):
