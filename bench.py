@@ -8,7 +8,8 @@ creature of the batch (controller + PID + world.Step(1/50, 180, 60) + reward/don
 prints ONE JSON line.  `--scaling weak` (default): every rank steps its own 65 536 creatures; `--scaling strong`:
 BASELINE.json's 65 536 creatures are split over the ranks.  Either way the only collective is one all-gather of fp64
 fitness at the end of each timed block.  The K steps are timed as a BLOCK (barrier + synchronize on both sides, max over
-ranks); blocks are repeated until the timed region is >= --min-time seconds (default 1 s) and the MEDIAN block is
+ranks); blocks are repeated until the timed region is >= --min-time seconds (default 5 s: long enough for an external
+utilisation sampler to see the GPU busy) and the MEDIAN block is
 reported (`config.blocks_ms` lists every block), so that a cold first block (fresh process on a fresh box) does not
 decide the figure.  Kernel-exact timing (HIP events) happens in a pass of its own AFTER the timed region; the secondary
 workloads (north_star's 8-module creatures, config 4) are measured in the same process and reported under `secondary`.
@@ -219,6 +220,37 @@ def host_cores():
     return n, quota
 
 
+def host_memory_budget():
+    """Bytes the CPU-baseline leg may spend on oracle worlds: a quarter of what the cgroup (v2 memory.max minus
+    memory.current, v1 limit_in_bytes minus usage_in_bytes) or the machine (MemAvailable) still has, at most 4 GiB."""
+    avail = None
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            with open(lim) as f:
+                v = f.read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                with open(cur) as f:
+                    avail = max(0, int(v) - int(f.read().strip()))
+                break
+        except Exception:  # noqa: BLE001
+            continue
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    m = int(line.split()[1]) * 1024
+                    avail = m if avail is None else min(avail, m)
+    except Exception:  # noqa: BLE001
+        pass
+    if avail is None:
+        avail = 4 << 30
+    return int(min(avail // 4, 4 << 30))
+
+
+ORACLE_WORLD_BYTES = 600 * 1024   # sizeof(o_world) with O_MAX_BODY_CONTACTS = 32, rounded up
+
+
 def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
     """The oracle (C restatement of the reference's Box2D path, OpenMP over creatures) on a bounded sample of the same
     workload, over the SAME step window the GPU leg times: steps [settle, settle + window) after reset, as ONE continuous
@@ -253,7 +285,8 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
     window = int(max(100, min(window, 400)))
     est_rate = one_thread * cores * 0.7
     want = int(budget_s * est_rate / (settle + window))
-    sample = sample_of(min(total, max(256, 48 * cores, min(want, 8192))))
+    mem_cap = max(64, host_memory_budget() // ORACLE_WORLD_BYTES)   # (the worlds of the window are alive at once)
+    sample = sample_of(min(total, mem_cap, max(256, 48 * cores, min(want, 8192))))
     n = sample["n_envs"]
     # (the sample is capped: a longer window of the same creatures fills the budget instead -- about 10-20 s of CPU work)
     window = int(max(window, min(budget_s * est_rate / n - settle, 800)))
@@ -334,6 +367,7 @@ def timed_blocks(run_block, steps, min_time, max_blocks, sync, reduce_max):
 
 
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -347,7 +381,7 @@ def main():
                     help="env-steps per C-ABI step call (one call = that many kernel sequences queued on the streams)")
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
-    ap.add_argument("--min-time", type=float, default=1.0,
+    ap.add_argument("--min-time", type=float, default=5.0,
                     help="repeat the --steps block until the timed region is at least this long (seconds); the median block is reported")
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -406,6 +440,7 @@ def main():
     if args.workload == "lsystem" and world == 1 and not args.no_secondary and n_envs == 65536 and not args.discrete:
         for wl in ("chain8", "cppn_hardcore"):
             secondary_in[wl] = build_population(wl, 65536, 0)
+    t_genomes = time.perf_counter()
     if not single:
         morphs, workload_desc = finish_population(prep)
     secondary_in = {wl: finish_population(p) for wl, p in secondary_in.items()}
@@ -430,6 +465,7 @@ def main():
 
     hard = args.workload == "cppn_hardcore"
     flat = not hard and not single
+    t_compiled = time.perf_counter()
     env = make_env(morphs, dev, hard, flat, args.discrete)
     spl = max(1, args.steps_per_launch)
     run = stepper(env, spl)
@@ -458,6 +494,11 @@ def main():
         args.settle = args.warmup = 0
     run(args.settle)
     run(args.warmup)
+    sync()
+    t_first_block = time.perf_counter()   # every rank is here: the timed blocks start now
+    startup = {"genomes_s": round(t_genomes - t_start, 2), "native_compile_and_rendezvous_s": round(t_compiled - t_genomes, 2),
+               "upload_settle_warmup_s": round(t_first_block - t_compiled, 2), "to_first_block_s": round(t_first_block - t_start, 2),
+               "host_cores": host_cores()[0]}
     if generation:
         from gym_rem2d_amd.evaluate import EPISODE_CAP
         sync()
@@ -553,6 +594,7 @@ def main():
             "value": total * args.steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "creatures_total": total,   # the population `value` is quoted on (weak scaling: 65 536 PER GPU, see `scaling`)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -578,6 +620,7 @@ def main():
                        "blocks": len(blocks), "blocks_ms": [round(x * 1e3, 3) for x in blocks],
                        "block_ms_median": dt * 1e3, "block_ms_first": blocks[0] * 1e3, "block_ms_min": min(blocks) * 1e3,
                        "timed_region_s": float(sum(blocks)),
+                       "startup": startup,   # wall seconds of this rank from process start to the first timed block
                        "solver_errors": err},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,

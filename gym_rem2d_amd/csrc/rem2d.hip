@@ -732,11 +732,11 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
     if (P.velpost) {
         if (timed) {
-            hipExtLaunchKernelGGL(rem2d_velpost_kernel, grid, block, 0, st, w0->evPool[w0->evUsed].first, w0->evPool[w0->evUsed].second, 0,
-                                  P.B, P.A, P.V);
+            hipExtLaunchKernelGGL(rem2d_velpost_kernel, grid, dim3(WAVE * REM2D_VELPOST_WAVES), 0, st, w0->evPool[w0->evUsed].first,
+                                  w0->evPool[w0->evUsed].second, 0, P.B, P.A, P.V);
             w0->evUsed += 1;
         } else {
-            hipLaunchKernelGGL(rem2d_velpost_kernel, grid, block, 0, st, P.B, P.A, P.V);
+            hipLaunchKernelGGL(rem2d_velpost_kernel, grid, dim3(WAVE * REM2D_VELPOST_WAVES), 0, st, P.B, P.A, P.V);
         }
     } else {
         if (timed) {

@@ -681,8 +681,12 @@ struct VelPostShared {
         PosShared p;
     };
 };
-__global__ __launch_bounds__(WAVE, 4) void rem2d_velpost_kernel(Batch B, StepArgs A, Vel4Args V) {
+#ifndef REM2D_VELPOST_WAVES
+#define REM2D_VELPOST_WAVES 1
+#endif
+__global__ __launch_bounds__(WAVE * REM2D_VELPOST_WAVES, 4) void rem2d_velpost_kernel(Batch B, StepArgs A, Vel4Args V) {
     __shared__ VelPostShared sh;
+    if (REM2D_VELPOST_WAVES > 1 && threadIdx.x >= WAVE) return; // (experiment: what do idle helper wavefronts per block cost?)
     unsigned block = blockIdx.x;
     const int b = batch_find(B, block);
     {

@@ -270,9 +270,10 @@ def test_bench_json_contract(need_gpu):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    # blocks of exactly `steps` env-steps, repeated until the timed region is >= --min-time (default 1 s); value = median
+    # blocks of exactly `steps` env-steps, repeated until the timed region is >= --min-time (default 5 s); value = median
     cfg = d["config"]
-    assert cfg["blocks"] == len(cfg["blocks_ms"]) >= 1 and cfg["timed_region_s"] >= 1.0
+    assert cfg["blocks"] == len(cfg["blocks_ms"]) >= 1 and (cfg["timed_region_s"] >= 5.0 or cfg["blocks"] == 400)
+    assert d["creatures_total"] == cfg["creatures_total"] == 1024 and cfg["startup"]["to_first_block_s"] > 0
     import numpy as np
     assert abs(d["ms_per_step"] * d["steps"] - float(np.median(cfg["blocks_ms"]))) < 1e-2
     assert abs(d["value"] - cfg["creatures_total"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
@@ -312,14 +313,52 @@ def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
-def _plank_population():
+def _plank_population(half_length=2.2):
     from gym_rem2d_amd import synthetic
     m = synthetic.chain_population(4, 2, "left")
     hx = m.arrays["hx"].reshape(4, m.lanes)
     hy = m.arrays["hy"].reshape(4, m.lanes)
     ang = m.arrays["angle"].reshape(4, m.lanes)
-    hx[2, 0], hy[2, 0], ang[2, 0] = 0.1, 2.2, np.float32(np.pi / 2)   # creature 2: a 4.4 m plank lying across ~9 edges
+    hx[2, 0], hy[2, 0], ang[2, 0] = 0.1, half_length, np.float32(np.pi / 2)   # creature 2: a 4.4 m plank lying across ~9 edges
     return m
+
+
+def test_creature_beyond_the_wide_build_gets_the_defined_penalty(need_gpu, oracle, flat_terrain):
+    """Box2D has no contact cap (Modular2DEnv.py:634); the engine has two tiers (24 / 6, then 32 / 12 pair / solver slots per
+    body).  A hand-built 7.6 m plank -- seven times the largest box the reference's classes can produce -- rests on more
+    than 12 terrain edges: beyond both.  With on_error="penalty" (what the EA loops use) the episode completes, the plank
+    gets evaluate.UNRESOLVED_FITNESS and is named in ``env.last_unresolved``; every other creature gets the oracle's
+    fitness bit for bit, and the oracle -- asked how many touching manifolds its bodies held while the fitness was open --
+    agrees on WHO is beyond the tiers, i.e. on every fitness under the same rule.  on_error="fallback" still raises."""
+    import pytest
+    import warnings
+    from conftest import oracle_terrain
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import UNRESOLVED_FITNESS, SolverOverflow, run_episode
+    m = _plank_population(3.8)
+    ref = oracle.batch_run_caps(oracle_terrain(oracle, flat_terrain), m.as_dict(), 150, n_threads=2, flags=oracle.FLAG_CONTINUOUS)
+    pairs_cap, touch_cap = _lib.capacity(wide=True)
+    beyond = (ref["caps"][:, 0] > pairs_cap) | (ref["caps"][:, 1] > touch_cap) | (ref["caps"][:, 2] > 0)
+    assert beyond.tolist() == [False, False, True, False] and ref["caps"][2, 1] > touch_cap >= ref["caps"][[0, 1, 3], 1].max()
+    want = np.where(beyond, UNRESOLVED_FITNESS, ref["fitness"])
+    env = BatchedModular2D(flat=True)
+    env.reset_morphology(m)
+    with pytest.warns(UserWarning, match="UNRESOLVED_FITNESS"):
+        fit = run_episode(env, max_steps=150, on_error="penalty")
+    assert env.last_unresolved == [2] and env.last_overflow == [2]
+    assert np.array_equal(fit.cpu().numpy(), want) and ref["fitness"][2] != UNRESOLVED_FITNESS
+    env.reset_morphology(m)
+    with pytest.raises(SolverOverflow):
+        run_episode(env, max_steps=150)
+    env.close()
+    # the EA's own evaluator path (run_ea's default evaluate_batch, population.gpu_evaluator) runs in penalty mode: a
+    # generation of ordinary individuals completes and reports nothing unresolved
+    from gym_rem2d_amd import ea
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")       # (no penalty warning for reference-legal creatures)
+        pop, hist = ea.run_ea(ea.make_config(population_size=24, encoding="lsystem"), seed=5, n_generations=1, log=None)
+    assert len(pop) == 24 and ea.run_ea.last_unresolved == [[], []]
 
 
 def test_solver_overflow_falls_back_to_the_wide_build(need_gpu, oracle, flat_terrain):
