@@ -722,12 +722,18 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 // (hipExtLaunchKernelGGL's start / stop events bracket exactly the kernel, which is what rocprofv3 --kernel-trace
 // reports; events recorded on the stream around the launch also count the dispatch gaps) and the whole sequence a pair
 // of stream events.
+#ifndef REM2D_SHAPE1_WPS
+#define REM2D_SHAPE1_WPS 3 // wavefronts per SIMD the 128-body tile shape is compiled for
+#endif
+#ifndef REM2D_SHAPE1_PAIR
+#define REM2D_SHAPE1_PAIR false
+#endif
 static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     rem2d_world *w0 = P.w0;
     const dim3 grid(P.blocks), block(WAVE);
     const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                            hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
-    if (P.launchShape == 3) hipLaunchKernelGGL(rem2d_pre_multi_kernel<4>, grid, block, 0, st, P.B, P.A);
+    if (P.launchShape == 3 || (P.launchShape == 1 && REM2D_SHAPE1_WPS >= 4)) hipLaunchKernelGGL(rem2d_pre_multi_kernel<4>, grid, block, 0, st, P.B, P.A);
     else hipLaunchKernelGGL(rem2d_pre_multi_kernel<3>, grid, block, 0, st, P.B, P.A);
     const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
     if (P.velpost) {
@@ -743,14 +749,14 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
             hipEvent_t e0 = w0->evPool[w0->evUsed].first, e1 = w0->evPool[w0->evUsed].second;
             switch (P.launchShape) {
             case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-            case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             }
             w0->evUsed += 1;
         } else {
             switch (P.launchShape) {
             case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-            case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             }
         }
