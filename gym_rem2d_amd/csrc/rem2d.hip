@@ -723,10 +723,10 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 // reports; events recorded on the stream around the launch also count the dispatch gaps) and the whole sequence a pair
 // of stream events.
 #ifndef REM2D_SHAPE1_WPS
-#define REM2D_SHAPE1_WPS 3 // wavefronts per SIMD the 128-body tile shape is compiled for
+#define REM2D_SHAPE1_WPS 4 // wavefronts per SIMD the 128-body tile shape is compiled for
 #endif
 #ifndef REM2D_SHAPE1_PAIR
-#define REM2D_SHAPE1_PAIR false
+#define REM2D_SHAPE1_PAIR true
 #endif
 static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     rem2d_world *w0 = P.w0;

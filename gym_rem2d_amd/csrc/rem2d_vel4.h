@@ -243,6 +243,11 @@ template <int SETS, int PASSES, int CSETS, bool CPAIR>
 DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsigned tile, int K, Vel4Shared<SETS, PASSES> &sh) {
     const int lane = threadIdx.x;
     const unsigned Lp = S.Lp;
+    // FLEX (one or two joint register sets): a joint whose phase's own set is full takes a lane of the other set, and the tick
+    // loop looks at every set in every tick -- so a tile may rotate its creatures' schedules and take the period P + 1 (both
+    // move joints between phases, hence between sets) without ever breaking the 64-joints-per-set rule the host planned for.
+    // The four-set shape keeps the host's static phase -> set map (one inlined joint slot per phase instead of four).
+    constexpr bool FLEX = SETS <= 2;
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
     const unsigned long long rEntry = (V4_DBG(A) & (16 | 64)) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
@@ -355,7 +360,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
             }
             const bool solve = (misc[p] & 0x100) != 0;
             const int nT = solve ? (misc[p] & 0xff) : 0;
-            if (SETS == 1) {
+            if (FLEX) {
                 const int cph = offB[p] % Pc;
                 int heavyPhase = 0, heavy = 0; // the creature's phase with the most manifolds on one body (ties: the first)
 #pragma unroll
@@ -386,7 +391,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         // about as much as a light one (800): only a gain of two sub-slots is worth a tick.  (Longer periods still -- up to
         // the creatures' round count, where every window contains one common tick -- need the tick loop rolled instead of
         // unrolled per phase; measured: the rolled loop costs 4 % per tick, more than the few tiles it helps gain.)
-        if (SETS == 1 && P < V4_PHASES && subsP >= 3) {
+        if (FLEX && P < V4_PHASES && subsP >= 3) {
             const int subsQ = plan(P + 1);
             if (subsQ + 2 <= subsP) P = P + 1;
             else (void)plan(P); // (back to the plan for P)
@@ -411,15 +416,33 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         const int nT = solve ? (misc[p] & 0xff) : 0;
         const int jr = (sched[p] & 0xff) + delta[p];
         const int phase = jr % P;
+        if (!FLEX) {
 #pragma unroll
-        for (int s = 0; s < SETS; ++s) {
-            const unsigned long long m = __ballot(hasJ && phase % SETS == s);
-            if (hasJ && phase % SETS == s) {
-                const int rank = jcount[s] + __popcll(m & below);
-                if (rank < WAVE) sh.jmap[s][rank] = (unsigned short)bl;
-                else err = REM2D_ERR_SOLVER_OVERFLOW; // the tile breaks the host's rule (<= 64 joints per register set)
+            for (int s = 0; s < SETS; ++s) {
+                const unsigned long long m = __ballot(hasJ && phase % SETS == s);
+                if (hasJ && phase % SETS == s) {
+                    const int rank = jcount[s] + __popcll(m & below);
+                    if (rank < WAVE) sh.jmap[s][rank] = (unsigned short)bl;
+                    else err = REM2D_ERR_SOLVER_OVERFLOW; // the tile breaks the host's rule (<= 64 joints per register set)
+                }
+                jcount[s] += __popcll(m);
             }
-            jcount[s] += __popcll(m);
+        } else {
+            bool placedJ = !hasJ;
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) {       // k-th choice of set: the phase's own first, then the next one with room
+#pragma unroll
+                for (int s = 0; s < SETS; ++s) {
+                    const bool want = !placedJ && (phase + k) % SETS == s;
+                    const unsigned long long m = __ballot(want);
+                    if (want) {
+                        const int rank = jcount[s] + __popcll(m & below);
+                        if (rank < WAVE) { sh.jmap[s][rank] = (unsigned short)bl; placedJ = true; }
+                    }
+                    jcount[s] = min(WAVE, jcount[s] + __popcll(m));
+                }
+            }
+            if (!placedJ) err = REM2D_ERR_SOLVER_OVERFLOW; // more joints than the tile's register sets hold in all (host rule broken)
         }
         if (hasJ && phase >= V4_PHASES) err = REM2D_ERR_SOLVER_OVERFLOW;
         const int off = offB[p] + delta[p];
@@ -554,10 +577,21 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                 if (s < P) {
                     const int tick = base + s;
                     if (stamp) t0 = __builtin_amdgcn_s_memtime();
-                    // the joints of phase s: register set s mod SETS, the lanes whose joint has that phase
-                    JointT &Js = J[s % SETS];
-                    if (joints && V4_VALID(Js.key) && (SETS == V4_PHASES || V4_JPHASE(Js.key) == s) &&
-                        (unsigned)(tick - V4_JROUND(Js.key)) < (unsigned)span) v4_joint_slot(Js, sh);
+                    // the joints of phase s: register set s mod SETS, the lanes whose joint has that phase (FLEX: then the other
+                    // set's lanes of that phase -- joints that did not fit their own set; two joints of one tick never share a body)
+                    {
+                        JointT &Js = J[s % SETS];
+                        if (joints && V4_VALID(Js.key) && (SETS == V4_PHASES || V4_JPHASE(Js.key) == s) &&
+                            (unsigned)(tick - V4_JROUND(Js.key)) < (unsigned)span) v4_joint_slot(Js, sh);
+                    }
+                    if (FLEX && SETS > 1) {
+#pragma unroll
+                        for (int q = 1; q < SETS; ++q) {
+                            JointT &Jo = J[(s + q) % SETS];
+                            if (joints && V4_VALID(Jo.key) && V4_JPHASE(Jo.key) == s &&
+                                (unsigned)(tick - V4_JROUND(Jo.key)) < (unsigned)span) v4_joint_slot(Jo, sh);
+                        }
+                    }
                     lds_sync();
                     if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tJ += t1 - t0; }
                     v4_contact_subslots<CSETS, CPAIR>(S, C, sh, tb0, lane, NC, spill, pair, subMax[s], s, tick, span, mu);

@@ -74,7 +74,8 @@ def group_streams(device, n):
 
 class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
-    BIG_POPULATION = 160000     # creatures per GPU from which the 256-lane tiles of the velocity kernel pay
+    BIG_POPULATION = 131072     # creatures per GPU from which the 128-lane tiles of the velocity kernel pay (round 4: 2 joint
+                                # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
     RETILE_POPULATION = 98304   # ... from which dealing the creatures to the position kernel's wavefronts anew every step
                                 # (REM2D_FLAG_RETILE) pays: +4.4 % at 131 072, -5 % at 65 536 (profiles/r03_retile.txt)
 
@@ -179,14 +180,14 @@ class BatchedModular2D:
                 groups = 4 if blocks >= 512 else 1   # (8 192 / 16 384 / 24 576 L-system creatures: +13 / +11 / +15 % over one)
             else:
                 groups = 3 if blocks >= 6144 else (2 if blocks >= 3072 else 1)
-        # Tile shape of the velocity kernel: 64-lane tiles up to ~150 000 creatures, 256-lane tiles beyond (see __init__).
+        # Tile shape of the velocity kernel: 64-lane tiles up to ~130 000 creatures, 128-lane tiles beyond (see __init__).
         # Fixed-morphology populations (every creature the same tree: the north-star's "8-module creatures") are the
         # exception: all creatures of a tile need the same slots per iteration, so a bigger tile costs no more per
         # iteration and halves the wavefronts -- 128-lane tiles: 170 M instead of 136 M env-steps/s for 65 536 8-module
         # chains -- once the 64-lane tiles of a step group would no longer fit the chip at once.
         shape = self.tile_shape
         if shape is None and _lib.env_tile_shape() is None:
-            shape = 0 if n_envs >= self.BIG_POPULATION else 3
+            shape = 1 if n_envs >= self.BIG_POPULATION else 3
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
                 shape = 1
         self._tile_shape_used = shape

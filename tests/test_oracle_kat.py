@@ -570,3 +570,46 @@ def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sanitized oracle OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_contact_capacity_bound_for_reference_legal_modules(oracle):
+    """Box2D has no cap on a body's contacts; the HIP builds have two tiers (24 / 6, then 32 / 12 pair / solver slots per
+    body, include/rem2d.h).  DESIGN.md 8 argues from the reference's constants that no module its classes can produce
+    reaches the SECOND tier's limits; this test (a) re-derives that bound from the same constants and (b) looks at what the
+    oracle's bodies really hold (rem2d_oracle_batch_run_caps: high-water marks of pairs / touching manifolds per body) on
+    populations of all three encodings, mutated to the size limits, on rough and hardcore terrain."""
+    import math
+    from gym_rem2d_amd import make_terrain, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    from gym_rem2d_amd.modules import Circular2D, Standard2D
+    # ---- (a) the bound.  Largest extent of a module: the diagonal of the largest box (limitWH, simple_module.py:55-68) + its
+    # polygon radius on both sides, or the largest circle's diameter
+    extent = max(math.hypot(max(Standard2D.MAX_WIDTH, 0.2), max(Standard2D.MAX_HEIGHT, 0.8)) + 2 * 0.01, 2 * Circular2D.MAX_RADIUS)
+    pitch = 14.0 / 30.0                                     # TERRAIN_STEP (Modular2DEnv.py:57)
+    touch_edges = math.ceil((extent + 2 * 0.02) / pitch) + 1     # edges within the total contact radius of the body's x-range
+    touch_polys = 2                                         # obstacles are >= 5 grid steps apart (TERRAIN_GRASS / 2): two stair steps at most
+    assert touch_edges + touch_polys <= 12, (touch_edges, touch_polys)
+    # pairs: fat AABB = swept tight AABB (extent + |dx|) + 2 * aabbExtension + aabbMultiplier * |dx|, |dx| <= maxTranslation
+    fat = extent + 2.0 + 2 * 0.1 + 2.0 * 2.0
+    pair_edges = math.ceil((fat + 2 * (0.01 + 0.1)) / pitch) + 1
+    pair_polys = 6                                          # a staircase has <= 5 steps (Modular2DEnv.py:256-275), + one more obstacle box
+    assert pair_edges + pair_polys <= 32, (pair_edges, pair_polys)
+    # ---- (b) observed
+    worst = np.zeros(3, dtype=np.int64)
+    for hard in (False, True):
+        terrain = make_terrain(4, hardcore=hard)
+        ot = oracle_terrain(oracle, terrain)
+        specs = synthetic.lsystem_specs(range(120), mutate_odd=True) + synthetic.cppn_specs(range(120)) + synthetic.direct_specs(range(60))
+        m = Morphology.from_specs(specs, 32)
+        # the size limits themselves: every box 1 x 1, every circle r = 0.5
+        box, circ = m.arrays["shape"] == 1, m.arrays["shape"] == 2
+        big = Morphology(m.n_envs, m.lanes)
+        for k, v in m.arrays.items():
+            big.arrays[k][:] = v
+        big.arrays["hx"][box] = big.arrays["hy"][box] = 0.5
+        big.arrays["hx"][circ] = 0.5
+        for pop in (m, big):
+            caps = oracle.batch_run_caps(ot, pop.as_dict(), 400, n_threads=8, flags=oracle.FLAG_CONTINUOUS)["caps"]
+            worst = np.maximum(worst, caps.max(axis=0))
+    assert worst[2] == 0                                    # the oracle itself never refused a pair
+    assert worst[0] <= 24 and worst[1] <= 12, worst         # within the first tier's pairs, the second tier's solver slots

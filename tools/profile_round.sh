@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profiles behind bench.py's roofline block, collected on the GPU box (gpurun).  Separate passes: --stats, then the two
 # HBM counters, then the SQ counters (gpurun refuses --pmc combined with the trace domains other than --kernel-trace).
-# usage: tools/profile_round.sh r03   -> gpurun_out/<tag>_prof/{stats,fetch,write,sq}  + summaries in gpurun_out/<tag>_prof/
+# usage: tools/profile_round.sh r04   -> gpurun_out/<tag>_prof/{stats,fetch,write,sq}  + summaries in gpurun_out/<tag>_prof/
 # The profiled command is the headline workload alone (--no-secondary), one timed block (--min-time 0): its LAST dispatches
 # are the timed block and the kernel-timing pass that follows it (the same steps of the same population).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,14 +1,14 @@
 #!/bin/bash
-# Everything measured for a round, on the GPU box: gpurun --timeout 2400 -- 'bash tools/round_gpu_run.sh r03_final'
+# Everything measured for a round, on the GPU box: gpurun --timeout 3000 -- 'bash tools/round_gpu_run.sh r04_final'
 # (each command under its own timeout so that a hang cannot eat the GPU budget).  The driver's command runs FIRST, as the
 # first GPU process of the lease (cold), then again (warm).
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20_cold.json 2> $O/bench_cold.err
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20.json 2>/dev/null
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-timeout 600 python3 bench.py --steps 200 --warmup 20 --no-secondary > $O/bench_default.json 2>/dev/null
+timeout 600 python3 bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline > $O/bench_default.json 2>/dev/null
 timeout 300 python3 bench.py --workload chain8 --no-cpu-baseline > $O/bench_chain8.json 2>/dev/null
 timeout 300 python3 bench.py --workload chain4 --no-cpu-baseline > $O/bench_chain4.json 2>/dev/null
 timeout 300 python3 bench.py --workload cppn_hardcore --no-cpu-baseline > $O/bench_cppn.json 2>/dev/null
@@ -16,8 +16,11 @@ timeout 300 python3 bench.py --workload generation --no-cpu-baseline > $O/bench_
 timeout 300 python3 bench.py --workload single --steps 1000 --warmup 0 --min-time 0 > $O/bench_single.json 2>/dev/null
 timeout 300 python3 bench.py --discrete --no-cpu-baseline --no-secondary > $O/bench_discrete.json 2>/dev/null
 timeout 300 python3 bench.py --pipeline 0 --no-cpu-baseline --no-secondary > $O/bench_fused.json 2>/dev/null
-timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_2ranks_1gpu_weak.json 2>/dev/null
-timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --scaling strong > $O/bench_2ranks_1gpu_strong.json 2>/dev/null
+timeout 600 python3 bench.py --workload generation --envs 1048576 --no-cpu-baseline > $O/bench_generation_1M_1gpu.json 2>/dev/null
+timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --min-time 2 > $O/bench_2ranks_1gpu_weak.json 2>/dev/null
+timeout 300 python3 bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --min-time 2 --scaling strong > $O/bench_2ranks_1gpu_strong.json 2>/dev/null
+timeout 600 python3 bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --min-time 2 > $O/bench_8ranks_1gpu_weak.json 2>/dev/null
+timeout 600 python3 bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --min-time 2 --scaling strong > $O/bench_8ranks_1gpu_strong.json 2>/dev/null
 timeout 120 python3 tools/bench_facade.py 2000 > $O/facade.txt 2>/dev/null
 for f in $O/bench_*.json; do python3 -c "
 import json,sys; d=json.load(open('$f')); c=d['config']; print('$f'.split('/')[-1], '%.2fM'%(d['value']/1e6), '%.3f ms/step'%d['ms_per_step'], 'blocks', c['blocks'], 'first %.1f med %.1f ms' % (c['block_ms_first'], c['block_ms_median']), 'err', c['solver_errors'], {k: round(v['value']/1e6,1) for k,v in (d.get('secondary') or {}).items()})"; done

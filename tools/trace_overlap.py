@@ -46,6 +46,24 @@ def main():
         cur += dlt
         last = t
     print("time share by number of kernels in flight: " + ", ".join("%d: %.1f%%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
+    # phase relation of the step groups: how many of the LONG kernels (velocity / position) run side by side, and how much
+    # of the time no long kernel of any group is running (all groups in their TOI / pre phase at once: the chip idles)
+    evl = []
+    for s, e, n, _ in rows:
+        if "velpost" in n or "vel4" in n or "post_multi" in n or "step_multi" in n:
+            evl.append((s, 1))
+            evl.append((e, -1))
+    if evl:
+        evl.sort()
+        histl = defaultdict(int)
+        cur, last = 0, min(r[0] for r in rows)
+        for t, dlt in evl:
+            histl[cur] += t - last
+            cur += dlt
+            last = t
+        histl[cur] += max(r[1] for r in rows) - last
+        print("time share by number of velocity / position kernels in flight: " +
+              ", ".join("%d: %.1f%%" % (k, 100.0 * v / span) for k, v in sorted(histl.items())))
     per = defaultdict(list)
     q = defaultdict(int)
     for s, e, n, qu in rows:
