@@ -45,7 +45,7 @@ def env_options():
 
 
 def env_tile_shape():
-    """REM2D_TILE_SHAPE (0 / 1 / 3) as an experiment override of the tile shape, or None."""
+    """REM2D_TILE_SHAPE (0 .. 4) as an experiment override of the tile shape, or None."""
     v = os.environ.get("REM2D_TILE_SHAPE", "")
     return int(v) if v != "" else None
 
@@ -223,7 +223,7 @@ def lib(wide=False):
 
 def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_shape=-1):
     """Tile plan of the velocity kernel for one morphology batch (rem2d_plan_tiles_shape): int32 tile starts
-    [n_tiles + 1].  tile_shape: 0 / 1 / 3, or -1 for the default (3); max_creatures 0: the library's default cap unless
+    [n_tiles + 1].  tile_shape: 0 .. 4, or -1 for the default (3); max_creatures 0: the library's default cap unless
     REM2D_TILE_CREATURES overrides it (experiments)."""
     import numpy as np
     parent = np.ascontiguousarray(parent, dtype=np.int32)

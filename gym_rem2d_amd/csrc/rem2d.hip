@@ -133,13 +133,30 @@ struct rem2d_world {
 };
 
 // Tile shape of rem2d_vel4_kernel (rem2d_world_set_tile_shape; rem2d_vel4.h explains the trade-off):
-//   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 3 waves/SIMD
+//   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 4 waves/SIMD (round 4)
+//   2: 192 bodies, 3 + 1 sets, 3 waves/SIMD (round 4)
 //   3: 64 bodies, 1 + 1 sets, 4 waves/SIMD (default: measured fastest on config 3; the same at 5 waves/SIMD spills: 24.7 M)
-struct TileShape { int sets, passes, csets; };
+//   4: 128 bodies, 2 + 1 sets, 3 waves/SIMD with the static phase -> set map of rounds 2-3: what fixed-morphology populations
+//      want (every creature the same schedule: nothing to rotate, and the 8-module chains are 5 % faster with it, 186 vs 176 M)
+// Shapes 1-3 place joints flexibly (rem2d_vel4.h FLEX): any tile within 64 joints per set IN ALL fits.
+struct TileShape { int sets, passes, csets, flex; };
+#define REM2D_TILE_SHAPES 5
 #define DEFAULT_TILE_SHAPE 3
 static TileShape tile_shape(int id) {
-    static const TileShape shapes[4] = {{4, 4, 2}, {2, 2, 1}, {1, 1, 1}, {1, 1, 1}}; // [2] unused
-    return shapes[(id == 0 || id == 1) ? id : 3];
+    static const TileShape shapes[REM2D_TILE_SHAPES] = {{4, 4, 2, 0}, {2, 2, 1, 1}, {3, 3, 1, 1}, {1, 1, 1, 1}, {2, 2, 1, 0}};
+    return shapes[(id >= 0 && id < REM2D_TILE_SHAPES) ? id : 3];
+}
+static bool tile_shape_ok(int id) { return id >= 0 && id < REM2D_TILE_SHAPES; }
+// which kernel runs a merged launch of worlds planned for different shapes: the one that takes every world's tiles (a tile
+// planned under the static phase -> set map fits a flexible kernel of the same size, not the other way round)
+static int tile_shape_rank(int id) { return id == 3 ? 0 : (id == 4 ? 1 : (id == 1 ? 2 : (id == 2 ? 3 : 4))); }
+// creatures per tile of the default plan (valid for every morphology of `lanes` lanes per creature)
+static int default_tile_creatures(const TileShape &shp, int lanes) {
+    // flexible shapes: a creature has fewer joints than lanes, so passes * 64 lanes never exceed sets * 64 joints (passes <= sets);
+    // four sets = one phase per set: 128 / lanes creatures never have more than 64 joints in a phase
+    int per = (shp.flex ? shp.passes * WAVE : (shp.sets >= 4 ? 128 : 64)) / lanes;
+    if (per * lanes > shp.passes * WAVE) per = shp.passes * WAVE / lanes;
+    return per < 1 ? 1 : per;
 }
 // Launch options of a world (include/rem2d.h REM2D_OPT_*): defaults and valid ranges.  None of them changes a result; the
 // library reads no environment variable -- hosts that want overrides for experiments pass them here (gym_rem2d_amd._lib
@@ -269,13 +286,8 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     // (<= lanes / 2 of them), so 128 / lanes creatures never have more than 64 joints in a phase;
     // rem2d_world_set_tiles lets the host pack tiles tighter from the actual morphologies.
     {
-        // (with one joint set per lane a tile holds at most 64 joints: 64 / lanes creatures)
         w->tileShape = DEFAULT_TILE_SHAPE;
-        const TileShape shp = tile_shape(w->tileShape);
-        // 4 sets = one phase per set: 128 / lanes creatures; fewer sets share phases, so keep to 64 joints in all
-        int per = (shp.sets >= 4 ? 128 : 64) / cfg->lanes;
-        if (per * cfg->lanes > shp.passes * WAVE) per = shp.passes * WAVE / cfg->lanes;
-        if (per < 1) per = 1;
+        const int per = default_tile_creatures(tile_shape(w->tileShape), cfg->lanes);
         std::vector<int32_t> ts;
         for (int c = 0; c < L.Np; c += per) ts.push_back(c);
         ts.push_back(L.Np);
@@ -313,14 +325,11 @@ extern "C" int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_
 
 extern "C" int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape_sel) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
-    if (tile_shape_sel != 0 && tile_shape_sel != 1 && tile_shape_sel != 3) return fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");
+    if (!tile_shape_ok(tile_shape_sel)) return fail(REM2D_E_INVALID, "tile shape must be 0 .. 4");
     if (w->tileShape == tile_shape_sel) return REM2D_OK;
     w->tileShape = tile_shape_sel;
     // the tile table in place may not fit the new shape: back to the default plan, valid for every morphology
-    const TileShape shp = tile_shape(w->tileShape);
-    int per = (shp.sets >= 4 ? 128 : 64) / w->cfg.lanes;
-    if (per * w->cfg.lanes > shp.passes * WAVE) per = shp.passes * WAVE / w->cfg.lanes;
-    if (per < 1) per = 1;
+    const int per = default_tile_creatures(tile_shape(w->tileShape), w->cfg.lanes);
     std::vector<int32_t> ts;
     for (int c = 0; c < w->L.Np; c += per) ts.push_back(c);
     ts.push_back(w->L.Np);
@@ -387,8 +396,8 @@ extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jrou
                                       int32_t n_padded, int32_t max_creatures, int32_t tile_shape_sel, int32_t *tile_start_out,
                                       int32_t *n_tiles_out) {
     if (!parent || !jround || !tile_start_out || !n_tiles_out) return fail(REM2D_E_INVALID, "plan_tiles: NULL argument");
-    if (tile_shape_sel != -1 && tile_shape_sel != 0 && tile_shape_sel != 1 && tile_shape_sel != 3)
-        return fail(REM2D_E_INVALID, "plan_tiles: tile shape must be 0, 1, 3 or -1 (the default, 3)");
+    if (tile_shape_sel != -1 && !tile_shape_ok(tile_shape_sel))
+        return fail(REM2D_E_INVALID, "plan_tiles: tile shape must be 0 .. 4 or -1 (the default, 3)");
     const TileShape sh = tile_shape(tile_shape_sel < 0 ? DEFAULT_TILE_SHAPE : tile_shape_sel);
     const int maxLanes = sh.passes * WAVE;
     if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
@@ -437,7 +446,13 @@ extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jrou
                 for (int s = 0; s < V4_PHASES; ++s) c2[s] = cnt[s];
             }
             add_counts(e, P2, c2);
-            for (int s = 0; s < V4_PHASES; ++s) fits = fits && c2[s] <= WAVE;
+            if (sh.flex) { // flexible placement (rem2d_vel4.h FLEX): 64 joints per register set in all
+                int all = 0;
+                for (int s = 0; s < V4_PHASES; ++s) all += c2[s];
+                fits = fits && all <= sh.sets * WAVE;
+            } else {
+                for (int s = 0; s < V4_PHASES; ++s) fits = fits && c2[s] <= WAVE;
+            }
         }
         if (!fits && e > first) { // close the tile before e, start a new one with e
             tile_start_out[++nt] = e;
@@ -697,7 +712,7 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
     P.launchShape = 3;
     for (int i = 0; i < n_worlds; ++i) {
         const int id = ws[i]->tileShape;
-        if (id == 0 || (id == 1 && P.launchShape == 3)) P.launchShape = id;
+        if (tile_shape_rank(id) > tile_shape_rank(P.launchShape)) P.launchShape = id;
     }
     P.velpost = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] != 0 && P.launchShape == 3;
     for (int i = 0; i < n_worlds; ++i)
@@ -733,6 +748,7 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     const dim3 grid(P.blocks), block(WAVE);
     const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                            hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
+    // (a merged launch of shapes 1 and 4: rank picks 1, whose flexible kernel takes the statically planned tiles too)
     if (P.launchShape == 3 || (P.launchShape == 1 && REM2D_SHAPE1_WPS >= 4)) hipLaunchKernelGGL(rem2d_pre_multi_kernel<4>, grid, block, 0, st, P.B, P.A);
     else hipLaunchKernelGGL(rem2d_pre_multi_kernel<3>, grid, block, 0, st, P.B, P.A);
     const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
@@ -750,6 +766,8 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
             switch (P.launchShape) {
             case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            case 2: hipExtLaunchKernelGGL((rem2d_vel4_kernel<3, 3, 1, 3, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            case 4: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             }
             w0->evUsed += 1;
@@ -757,6 +775,8 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
             switch (P.launchShape) {
             case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            case 2: hipLaunchKernelGGL((rem2d_vel4_kernel<3, 3, 1, 3, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            case 4: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             }
         }

@@ -239,15 +239,15 @@ DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsig
     }
 }
 
-template <int SETS, int PASSES, int CSETS, bool CPAIR>
+template <int SETS, int PASSES, int CSETS, bool CPAIR, bool FLEXP = true>
 DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsigned tile, int K, Vel4Shared<SETS, PASSES> &sh) {
     const int lane = threadIdx.x;
     const unsigned Lp = S.Lp;
-    // FLEX (one or two joint register sets): a joint whose phase's own set is full takes a lane of the other set, and the tick
+    // FLEX (up to three joint register sets): a joint whose phase's own set is full takes a lane of the other set, and the tick
     // loop looks at every set in every tick -- so a tile may rotate its creatures' schedules and take the period P + 1 (both
     // move joints between phases, hence between sets) without ever breaking the 64-joints-per-set rule the host planned for.
     // The four-set shape keeps the host's static phase -> set map (one inlined joint slot per phase instead of four).
-    constexpr bool FLEX = SETS <= 2;
+    constexpr bool FLEX = FLEXP && SETS <= 3;
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
     const unsigned long long rEntry = (V4_DBG(A) & (16 | 64)) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
@@ -690,14 +690,14 @@ struct Vel4Batch {
     int lanes[REM2D_MAX_BATCH];
     int n;
 };
-template <int SETS, int PASSES, int CSETS, int WPS, bool CPAIR>
+template <int SETS, int PASSES, int CSETS, int WPS, bool CPAIR, bool FLEXP = true>
 __global__ __launch_bounds__(WAVE, WPS) void rem2d_vel4_kernel(Vel4Batch B, Vel4Args A) {
     __shared__ Vel4Shared<SETS, PASSES> sh;
     unsigned tile = blockIdx.x;
     int b = 0;
     while (b + 1 < B.n && tile >= B.tileEnd[b]) ++b;
     if (b > 0) tile -= B.tileEnd[b - 1];
-    vel4_body<SETS, PASSES, CSETS, CPAIR>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
+    vel4_body<SETS, PASSES, CSETS, CPAIR, FLEXP>(B.S[b], B.friction[b], A, tile, B.lanes[b], sh);
 }
 
 // ---------------------------------------------------------------------------------------------------

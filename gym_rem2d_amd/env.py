@@ -189,7 +189,7 @@ class BatchedModular2D:
         if shape is None and _lib.env_tile_shape() is None:
             shape = 1 if n_envs >= self.BIG_POPULATION else 3
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
-                shape = 1
+                shape = 4   # (128-lane tiles with the static phase -> set map: nothing to rotate in a uniform population)
         self._tile_shape_used = shape
         retile = os.environ.get("REM2D_RETILE")
         retile = (n_envs >= self.RETILE_POPULATION and not all(_uniform(m) for m, _ in batches)) if retile is None else retile == "1"

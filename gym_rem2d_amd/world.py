@@ -95,7 +95,7 @@ class BatchedWorld:
 
     # ---- reset: upload the morphology and rebuild every world ----
     def reset(self, morph: Morphology, tile_shape=None):
-        """tile_shape: launch shape of the velocity kernel for this world (0 / 1 / 3, include/rem2d.h
+        """tile_shape: launch shape of the velocity kernel for this world (0 .. 4, include/rem2d.h
         rem2d_world_set_tile_shape); None keeps the world's current one (3 unless REM2D_TILE_SHAPE overrode it)."""
         if morph.n_envs != self.n_envs or morph.lanes != self.lanes:
             raise ValueError("morphology shape (%d x %d) does not match world (%d x %d)" %

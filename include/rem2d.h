@@ -191,12 +191,14 @@ int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_t
 int rem2d_plan_tiles(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                      int32_t max_creatures, int32_t *tile_start_out, int32_t *n_tiles_out);
 /* Tile shape of the velocity kernel for this world (again a launch shape without a counterpart in the reference):
- * 3 = 64 lanes per tile, one joint per kernel lane (4 wavefronts per SIMD; the default, fastest up to ~150 000 creatures
- * per GPU), 1 = 128 lanes, 0 = 256 lanes with one register set per schedule phase (2.4x fewer wave-instructions at 2
- * wavefronts per SIMD; faster once the population saturates the chip's instruction issue, from ~160 000 creatures per GPU on).  Replaces the tile table by the default plan of the new shape: call rem2d_world_set_tiles
+ * 3 = 64 lanes per tile, one joint per kernel lane (4 wavefronts per SIMD; the default, fastest up to ~130 000 creatures
+ * per GPU), 1 = 128 lanes with two joint register sets (4 wavefronts per SIMD, a third fewer wave-instructions: faster once
+ * instruction issue alone limits the step, from ~130 000 creatures per GPU on), 2 = 192 lanes with three sets (3 wavefronts
+ * per SIMD), 0 = 256 lanes with one register set per schedule phase (2 wavefronts per SIMD), 4 = 128 lanes with the static
+ * phase -> register-set map (3 wavefronts per SIMD: what fixed-morphology populations want).  Replaces the tile table by the default plan of the new shape: call rem2d_world_set_tiles
  * afterwards with a plan made for the same shape (rem2d_plan_tiles_shape).  Results do not depend on it. */
 int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape);
-/* rem2d_plan_tiles for a given tile shape (0, 1, 3; -1 = the default, 3) */
+/* rem2d_plan_tiles for a given tile shape (0 .. 4; -1 = the default, 3) */
 int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                            int32_t max_creatures, int32_t tile_shape, int32_t *tile_start_out, int32_t *n_tiles_out);
 

@@ -166,7 +166,7 @@ int rem2d_cpu_world_adopt(rem2d_cpu_world *w) {
 }
 int rem2d_cpu_world_set_tile_shape(rem2d_cpu_world *w, int32_t tile_shape) {
     if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
-    if (tile_shape != 0 && tile_shape != 1 && tile_shape != 3) return c_fail(REM2D_E_INVALID, "tile shape must be 0, 1 or 3");
+    if (tile_shape < 0 || tile_shape > 4) return c_fail(REM2D_E_INVALID, "tile shape must be 0 .. 4");
     return REM2D_OK; /* a launch shape: nothing to do on the CPU */
 }
 /* launch options (include/rem2d.h REM2D_OPT_*): kept and handed back, nothing to steer on the CPU; same range checks */

@@ -275,7 +275,7 @@ def test_full_size_chain8(gpu, oracle, flat_terrain):
     env.reset_morphology(synthetic.chain_population(N, 8, "left"))
     import os
     assert len(env.groups) == 3 and len(env.worlds) == 3
-    assert env._tile_shape_used == 1 or "REM2D_TILE_SHAPE" in os.environ   # (the suite is also run with the shape forced)
+    assert env._tile_shape_used == 4 or "REM2D_TILE_SHAPE" in os.environ   # (the suite is also run with the shape forced)
     for _ in range(steps // 25):
         env.step(25)
     torch.cuda.synchronize()
@@ -393,15 +393,15 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
     assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
 
 
-@pytest.mark.parametrize("variant", [{"pipeline": 0}, {"tile_shape": 0}, {"tile_shape": 1}, {"fuse_velpost": 0},
+@pytest.mark.parametrize("variant", [{"pipeline": 0}, {"tile_shape": 0}, {"tile_shape": 1}, {"tile_shape": 2}, {"tile_shape": 4}, {"fuse_velpost": 0},
                                      {"prio": 0, "heavy_per_wave": 2}],
-                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "velocity_and_position_in_two_launches",
-                              "no_issue_priority_two_toi_bodies_per_wavefront"])
+                         ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "tiles_192_bodies", "tiles_128_bodies_static_sets",
+                              "velocity_and_position_in_two_launches", "no_issue_priority_two_toi_bodies_per_wavefront"])
 def test_other_formulations_match_committed_digests(gpu, variant):
     """The library's switches are per-world launch options (rem2d_world_set_option / rem2d_world_set_tile_shape; it reads no
     environment variable), so every other formulation runs in this very process: the fused body-per-lane kernel of round 1
-    (pipeline 0) and the wider tile shapes of the velocity kernel (256 / 128 bodies per wavefront, 4 / 2 joint register
-    sets) reproduce the same committed digests as the default (which runs a block's velocity tiles and its position
+    (pipeline 0) and the wider tile shapes of the velocity kernel (256 / 192 / 128 bodies per wavefront, 4 / 3 / 2 joint
+    register sets; the latter two with flexible joint placement, rotation and period choice like the default) reproduce the same committed digests as the default (which runs a block's velocity tiles and its position
     iterations in one launch, rem2d_velpost_kernel); so do the two launches rem2d_vel4_kernel + rem2d_post_multi_kernel, and
     so does the default formulation without its scheduling hints (issue priority, one TOI body per wavefront)."""
     import json
