@@ -189,6 +189,7 @@ def lib(wide=False):
     L.rem2d_plan_tiles_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p]
     L.rem2d_world_set_tile_shape.argtypes = [C.c_void_p, C.c_int32]
+    L.rem2d_world_set_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rem2d_world_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.rem2d_world_get_option.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.rem2d_world_adopt.argtypes = [C.c_void_p]

@@ -336,6 +336,22 @@ extern "C" int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape_sel
     return rem2d_world_set_tiles(w, ts.data(), (int32_t)ts.size() - 1);
 }
 
+extern "C" int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream) {
+    if (!w) return fail(REM2D_E_INVALID, "world is NULL");
+    if (w->cfg.flags & REM2D_FLAG_RETILE) return fail(REM2D_E_INVALID, "set_order: the world deals its creatures itself (REM2D_FLAG_RETILE)");
+    HIP_TRY(hipSetDevice(w->cfg.device));
+    if (order_dev) {
+        // both halves (the REM2D_FLAG_RETILE machinery reads the first, swaps in the second): what the kernels read stays put
+        HIP_TRY(hipMemcpyAsync(w->S.order, order_dev, (size_t)w->L.Np * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIP_TRY(hipMemcpyAsync(w->S.order + w->L.Np, order_dev, (size_t)w->L.Np * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        w->S.flags |= REM2D_STATE_ORDERED;
+    } else {
+        w->S.flags &= ~REM2D_STATE_ORDERED;
+    }
+    w->epoch = next_epoch();
+    return REM2D_OK;
+}
+
 extern "C" int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
     if (key < 0 || key >= REM2D_OPT_COUNT) return fail(REM2D_E_INVALID, "set_option: unknown option");
@@ -716,7 +732,7 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
     }
     P.velpost = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] != 0 && P.launchShape == 3;
     for (int i = 0; i < n_worlds; ++i)
-        P.velpost = P.velpost && ws[i]->S.tileCap > 0 && !(ws[i]->cfg.flags & REM2D_FLAG_RETILE) && ws[i]->tileShape == 3;
+        P.velpost = P.velpost && ws[i]->S.tileCap > 0 && ws[i]->tileShape == 3; // (REM2D_FLAG_RETILE: tile slots and block slots go through the same creature order)
     P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     P.A.nSteps = 1;
     P.A.dt = dt;

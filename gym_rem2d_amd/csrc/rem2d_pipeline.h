@@ -253,8 +253,9 @@ DEV bool post_body(const State &S, const Terrain &T, const StepArgs &A, unsigned
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
     const unsigned slot = (block * WAVE + lane) / K;
-    const bool retile = (S.flags & REM2D_FLAG_RETILE) != 0;
-    const unsigned env = retile ? (unsigned)S.order[slot] : slot; // the creature this lane group handles in this step
+    const bool retile = (S.flags & REM2D_FLAG_RETILE) != 0;       // the kernel deals the creatures anew for the next step
+    const bool ordered = retile || (S.flags & REM2D_STATE_ORDERED) != 0;
+    const unsigned env = ordered ? (unsigned)S.order[slot] : slot; // the creature this lane group handles in this step
     const unsigned gl = env * K + sub;
     const unsigned Lp = S.Lp;
     const int misc = __float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + gl, 0));
@@ -398,7 +399,7 @@ template <int K> DEV void post_only_body(const State &S, const Terrain &T, const
 #endif
     (void)post_body<K, false>(S, T, A, block, psh);
 #ifdef REM2D_V4_PROBES
-    if (threadIdx.x == 0 && 2 * K <= WAVE && !(S.flags & REM2D_FLAG_RETILE)) {
+    if (threadIdx.x == 0 && 2 * K <= WAVE && !(S.flags & (REM2D_FLAG_RETILE | REM2D_STATE_ORDERED))) {
         const unsigned env = block * (WAVE / K) + 1;
         if (env < S.Np) EI(E_TOIEVENTS) = (int)(__builtin_amdgcn_s_memrealtime() - rEntry);
     }

@@ -95,6 +95,10 @@ struct State {
     // velocity + position launch (rem2d_velpost_kernel) finds the tiles of a block with it; 0 = irregular table
     int nTiles, tileCap;
 };
+// State::flags = rem2d_world_cfg::flags | internal bits:
+// the host installed a creature order (rem2d_world_set_order): slot e of the tile table / of a 64-lane block is creature
+// order[e], fixed until the host changes it (REM2D_FLAG_RETILE: the same indirection, re-dealt by the position kernel itself)
+#define REM2D_STATE_ORDERED 0x10000u
 // accessors (S, gl and env must be in scope where they are used)
 #define LF(f) (*(float *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))
 #define LI(f) (*(int *)(S.lane4 + (size_t)(f) * ((size_t)S.Lp * 4) + (gl) * 4u))

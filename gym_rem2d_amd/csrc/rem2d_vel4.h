@@ -49,6 +49,9 @@ template <int SETS, int PASSES> struct Vel4Shared {
     unsigned short jmap[SETS][WAVE];        // (set, lane) -> tile-local body id of the joint's child, 0xffff = none
     unsigned int cmap[PASSES * WAVE * KT];  // contact rank -> V4_C* key (body, sub-slot, manifold index, tick offset)
     int firstR[PASSES * WAVE], lastR[PASSES * WAVE]; // first / last joint round of every body (own joint and children's)
+    // tile-local body id -> lane index in the state arena.  Consecutive creatures unless the world deals its creatures anew
+    // every step (REM2D_FLAG_RETILE): then slot e of the tile table is creature order[e], for this kernel as for post
+    unsigned glmap[PASSES * WAVE];
 };
 
 // one joint: what the 180 iterations read (constants) and write (accumulated impulses).  The inverse inertias come
@@ -70,9 +73,9 @@ struct JointT {
 #define V4_JPHASE(k) (((k) >> 26) & 0x7)
 #define V4_VALID(k) ((k) < 0)
 
-DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, int P, int rotation, JointT &J) {
+DEV void v4_joint_load(const State &S, const unsigned *glmap, int K, int child, float h, int P, int rotation, JointT &J) {
     const unsigned Lp = S.Lp;
-    const unsigned gl = tb0 + (unsigned)child;
+    const unsigned gl = glmap[child];
     const int jA = (child & ~(K - 1)) + LI(L_PARENT);
     const int jround = (LI(L_JROUND) & 0xff) + rotation; // (its creature's schedule runs `rotation` ticks late)
     const unsigned jb = (unsigned)SCR_JREC_BASE * Lp + gl;
@@ -86,7 +89,7 @@ DEV void v4_joint_load(const State &S, unsigned tb0, int K, int child, float h, 
     J.maxMotorImpulse = h * LF(L_JTORQUE);
     float iA;
     {
-        const unsigned gl = tb0 + (unsigned)jA;
+        const unsigned gl = glmap[jA];
         J.mA = LF(L_INVM); iA = LF(L_INVI);
     }
     J.key = jA | (child << 8) | (jround << 16) | (limitState << 24) | ((jround % P) << 26) | (int)0x80000000;
@@ -198,7 +201,7 @@ static_assert(KT <= 16, "manifold index: 4 bits");
 
 // the contact sub-slots of the tick `tick` (phase ph): every manifold scheduled here, in the order of its body's list
 template <int CSETS, bool CPAIR, typename SH>
-DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsigned tb0, int lane, int NC, bool spill,
+DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, int lane, int NC, bool spill,
                              bool pair, int nsub, int ph, int tick, int span, float mu) {
     const unsigned Lp = S.Lp;
     for (int t = 0; t < nsub; ++t) {
@@ -225,7 +228,7 @@ DEV void v4_contact_subslots(const State &S, ContactT (&C)[CSETS], SH &sh, unsig
                 const int e = (int)sh.cmap[ci];
                 const int b = V4_CBODY(e);
                 if (V4_CSUB(e) != t || V4_CPHASE(e) != ph || !((unsigned)(tick - V4_COFF(e)) < (unsigned)span)) continue;
-                const unsigned gl = tb0 + (unsigned)b;
+                const unsigned gl = sh.glmap[b];
                 const unsigned cb = (unsigned)(SCR_CC_BASE + V4_CT(e) * CC_WORDS) * Lp + gl;
                 ContactC c;
                 cc_load(S, cb, c);
@@ -251,14 +254,14 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
     const unsigned long long rEntry = (V4_DBG(A) & (16 | 64)) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
-    const unsigned tb0 = (unsigned)c0 * (unsigned)K;
+    const bool retile = (S.flags & (REM2D_FLAG_RETILE | REM2D_STATE_ORDERED)) != 0;
     const int iters = A.velIters;
     const float h = A.dt, mu = friction;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (WAVE - lane));
     if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // pre skipped these creatures: nothing to solve, nothing handed over
         bool allFrozen = true;
         for (int e = c0 + lane; e < c1; e += WAVE) {
-            const unsigned env = (unsigned)e;
+            const unsigned env = retile ? (unsigned)S.order[e] : (unsigned)e;
             allFrozen = allFrozen && EI(E_FROZEN) != 0;
         }
         if (__all(allFrozen ? 1 : 0)) return;
@@ -272,7 +275,10 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
-        const unsigned gl = tb0 + (unsigned)bl;
+        // (a lane beyond the tile's bodies maps to its own slot of the next creatures: never dereferenced, bl < NB guards)
+        const unsigned ce = (unsigned)c0 + (unsigned)(bl / K);
+        const unsigned gl = ((retile && bl < NB) ? (unsigned)S.order[ce] : ce) * (unsigned)K + (unsigned)(bl & (K - 1));
+        sh.glmap[bl] = gl;
         sched[p] = 0; misc[p] = 0; parent[p] = -1;
         sh.firstR[bl] = 0x7fffffff;
         sh.lastR[bl] = -1;
@@ -487,7 +493,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     for (int s = 0; s < SETS; ++s) {
         J[s].key = 0;
         const int child = sh.jmap[s][lane];
-        if (child != 0xffff) v4_joint_load(S, tb0, K, child, h, P, sh.firstR[child], J[s]);
+        if (child != 0xffff) v4_joint_load(S, sh.glmap, K, child, h, P, sh.firstR[child], J[s]);
     }
     // ---------------- contact role: manifold `lane + 64 cs` of the tile; beyond CSETS * 64 through scratch ----------------
     ContactT C[CSETS];
@@ -507,7 +513,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         if (ci < NC) {
             const int e = (int)sh.cmap[ci];
             const int b = V4_CBODY(e), t = V4_CT(e);
-            const unsigned gl = tb0 + (unsigned)b;
+            const unsigned gl = sh.glmap[b];
             C[cs].key = e | (int)0x80000000;
             C[cs].mB = LF(L_INVM);
             cc_load(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, C[cs].c);
@@ -532,7 +538,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                 const int e = (int)sh.cmap[ci];
                 const int b = V4_CBODY(e);
                 if (V4_CT(e) != t) continue;
-                const unsigned gl = tb0 + (unsigned)b;
+                const unsigned gl = sh.glmap[b];
                 ContactC c;
                 cc_load(S, (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl, c);
                 V4Vel v = sh.vel[b];
@@ -594,7 +600,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
                     }
                     lds_sync();
                     if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tJ += t1 - t0; }
-                    v4_contact_subslots<CSETS, CPAIR>(S, C, sh, tb0, lane, NC, spill, pair, subMax[s], s, tick, span, mu);
+                    v4_contact_subslots<CSETS, CPAIR>(S, C, sh, lane, NC, spill, pair, subMax[s], s, tick, span, mu);
                     if (stamp) { tC += __builtin_amdgcn_s_memtime() - t1; nSub += subMax[s]; }
                 }
             }
@@ -623,7 +629,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     for (int cs = 0; cs < CSETS; ++cs) {
         if (V4_VALID(C[cs].key) && !(pair && (lane & 1))) { // (one lane of a pair stores)
             const int b = V4_CBODY(C[cs].key), t = V4_CT(C[cs].key);
-            const unsigned gl = tb0 + (unsigned)b;
+            const unsigned gl = sh.glmap[b];
             const slotpack_t sp = sp_load(S, (unsigned)SCR_MISC_BASE * Lp + gl);
             const unsigned o = SP_GET(sp, t) * Lp + gl;
             CF(C_N0, o) = C[cs].c.n0;
@@ -638,7 +644,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         for (int ci = CCAP + lane; ci < NC; ci += WAVE) {
             const int e = (int)sh.cmap[ci];
             const int b = V4_CBODY(e), t = V4_CT(e);
-            const unsigned gl = tb0 + (unsigned)b;
+            const unsigned gl = sh.glmap[b];
             const unsigned cb = (unsigned)(SCR_CC_BASE + t * CC_WORDS) * Lp + gl;
             const slotpack_t sp = sp_load(S, (unsigned)SCR_MISC_BASE * Lp + gl);
             const unsigned o = SP_GET(sp, t) * Lp + gl;
@@ -653,7 +659,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
 #pragma unroll
     for (int s = 0; s < SETS; ++s) {
         if (V4_VALID(J[s].key)) {
-            const unsigned gl = tb0 + (unsigned)V4_JB(J[s].key);
+            const unsigned gl = sh.glmap[V4_JB(J[s].key)];
             LF(L_JIMPX) = J[s].impX; LF(L_JIMPY) = J[s].impY; LF(L_JIMPZ) = J[s].impZ; LF(L_JMOTORIMP) = J[s].motorImp;
         }
     }
@@ -661,14 +667,14 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     for (int p = 0; p < PASSES; ++p) {
         const int bl = p * WAVE + lane;
         if (misc[p] & 0x100) {
-            const unsigned gl = tb0 + (unsigned)bl;
+            const unsigned gl = sh.glmap[bl];
             const V4Vel v = sh.vel[bl];
             LF(L_VX) = v.x; LF(L_VY) = v.y; LF(L_W) = v.w;
         }
     }
     err = wave_or(err);
     if (err && lane == 0) {
-        const unsigned env = (unsigned)c0;
+        const unsigned env = retile ? (unsigned)S.order[c0] : (unsigned)c0;
         atomicOr(&EI(E_ERR), err);
     }
     if ((V4_DBG(A) & 64) && lane == 0) { // diagnostic (tools/chain_probe.py): this wavefront's time in the kernel, 100 MHz ticks

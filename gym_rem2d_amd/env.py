@@ -106,6 +106,13 @@ class BatchedModular2D:
         self.groups, self.group_streams = [], []
         self._group_args = None
         self.use_graph = os.environ.get("REM2D_GRAPH", "0") == "1"   # replay every step call as a hipGraph
+        # Creature order by current cost (rebalance): every `rebalance_every` env-steps the creatures that used every position
+        # iteration in the last step are moved to the front of their world's order (a stable sort: the static schedule order
+        # survives within both classes), so that they share velocity tiles and position blocks.  0 (default): off -- measured
+        # +1.8 % on config 3, +2 % on the 131 072-creature generation against REM2D_FLAG_RETILE, but -3.7 % on config 4
+        # (profiles/r04_lane_fill_experiments.txt): not a policy yet.  REM2D_REBALANCE=<steps> switches it on (experiments).
+        self.rebalance_every = int(os.environ.get("REM2D_REBALANCE", "0"))
+        self._since_rebalance = 0
 
     def seed(self, seed=None):
         self._seed = seed
@@ -194,6 +201,10 @@ class BatchedModular2D:
         retile = os.environ.get("REM2D_RETILE")
         retile = (n_envs >= self.RETILE_POPULATION and not all(_uniform(m) for m, _ in batches)) if retile is None else retile == "1"
         self._world_flags = (self.flags | _lib.FLAG_RETILE) if retile else (self.flags & ~_lib.FLAG_RETILE)
+        self._rebalance_steps = max(0, self.rebalance_every)
+        if retile:
+            self._rebalance_steps = 0   # (the position kernel deals the creatures itself)
+        self._since_rebalance = 0
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
@@ -292,10 +303,27 @@ class BatchedModular2D:
                     w.step(n_steps)
             for st in self.streams:
                 cur.wait_stream(st)
+        if self._rebalance_steps > 0:
+            self._since_rebalance += int(n_steps)
+            if self._since_rebalance >= self._rebalance_steps:
+                self.rebalance()
         if len(self.worlds) == 1 and not self._compacted:
             w = self.worlds[0][0]
             return w.view("reward"), w.view("done") != 0
         return self._reward, self._done   # written by the step's own kernels (set_outputs in _upload)
+
+    def rebalance(self, pos_iters=60):
+        """Give every world a creature order by CURRENT cost (rem2d_world_set_order): the creatures that used all `pos_iters`
+        position iterations in the last step -- a joint at its limit pressed against the ground; the same creatures for many
+        steps -- go to the front, in their static order, the others follow in theirs.  A velocity tile / position block costs
+        what its most expensive creature costs, so the expensive ones should share wavefronts.  A few small torch kernels
+        per world, queued on the caller's stream like the steps; no effect on any result."""
+        self._since_rebalance = 0
+        for wi, (w, _) in enumerate(self.worlds):
+            if wi in self._inactive or (w.flags & _lib.FLAG_RETILE) or w.n_envs < 2 * (64 // min(64, w.lanes)):
+                continue
+            slow = w.view("positers") >= pos_iters
+            w.set_order(torch.sort((~slow).to(torch.uint8), stable=True).indices)
 
     def launch_info(self):
         """(tile shape, velocity tiles and position iterations in one launch?) of the first step group -- the library's own

@@ -49,6 +49,19 @@ class BatchedWorld:
         for name, value in dict(_lib.env_options(), **(options or {})).items():
             self.set_option(name, value)
 
+    def set_order(self, order):
+        """Install a creature order (rem2d_world_set_order): slot e of the velocity tiles / position blocks handles creature
+        order[e].  order: int tensor [n_envs] -- a permutation of the creatures -- on any device, or None for the identity.
+        Padding slots keep themselves.  A launch shape: results do not depend on it."""
+        if order is None:
+            self._order = None
+            self._check(self.L.rem2d_world_set_order(self.h, None, self._stream()))
+            return
+        full = torch.arange(self.n_envs_padded, dtype=torch.int32, device=self.device)
+        full[:self.n_envs] = order.to(device=self.device, dtype=torch.int32)
+        self._order = full   # (kept alive until the asynchronous copy has run)
+        self._check(self.L.rem2d_world_set_order(self.h, full.data_ptr(), self._stream()))
+
     def set_option(self, name, value):
         """A launch option of this world (``_lib.OPTIONS``: pipeline, fuse_velpost, prio, prio_t1, prio_t2, heavy_per_wave,
         debug); in a step group the first world's options steer the group's launches."""

@@ -29,7 +29,7 @@ extern "C" {
 
 #define REM2D_ABI_VERSION 8 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
-                               7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable) */
+                               7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar */
 
 enum {
     REM2D_OK = 0,
@@ -201,6 +201,18 @@ int rem2d_world_set_tile_shape(rem2d_world *w, int32_t tile_shape);
 /* rem2d_plan_tiles for a given tile shape (0 .. 4; -1 = the default, 3) */
 int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jround, int32_t n_envs, int32_t lanes, int32_t n_padded,
                            int32_t max_creatures, int32_t tile_shape, int32_t *tile_start_out, int32_t *n_tiles_out);
+
+/* Creature order of a world (a launch shape again, no counterpart in the reference, no effect on results: creatures are
+ * independent).  With an order installed, slot e of the velocity kernel's tile table and of the position kernel's 64-lane
+ * blocks is creature order_dev[e] instead of creature e: the host may keep creatures of similar CURRENT cost together -- a tile
+ * costs what its most expensive creature costs -- e.g. those that used every position iteration in the last steps
+ * (REM2D_F_POSITERS), which stay the same for many steps (gym_rem2d_amd.env.BatchedModular2D.rebalance does that every few
+ * dozen steps with a stable sort, so that the static schedule order survives within each class; REM2D_FLAG_RETILE is the
+ * same indirection re-dealt by the kernel itself in every step, in arrival order).  order_dev: DEVICE array of
+ * rem2d_padded_envs() int32, a permutation of 0 .. padded - 1 (the caller's responsibility), copied asynchronously on
+ * `stream`; NULL: back to the identity.  Refused for a world created with REM2D_FLAG_RETILE.  Any order is valid for the
+ * default tile plans; a plan made by rem2d_plan_tiles for specific morphologies must be made for the creatures in that order. */
+int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream);
 
 /* Launch options of a world.  Like the tile shape they are launch shapes / scheduling hints without a counterpart in the
  * reference (b2World::Step has no such knobs) and NO result depends on them: every combination reproduces the same bits

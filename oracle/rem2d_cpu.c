@@ -169,6 +169,13 @@ int rem2d_cpu_world_set_tile_shape(rem2d_cpu_world *w, int32_t tile_shape) {
     if (tile_shape < 0 || tile_shape > 4) return c_fail(REM2D_E_INVALID, "tile shape must be 0 .. 4");
     return REM2D_OK; /* a launch shape: nothing to do on the CPU */
 }
+/* a creature order is a launch shape: nothing to do on the CPU (the twin steps creature by creature) */
+int rem2d_cpu_world_set_order(rem2d_cpu_world *w, const int32_t *order, void *stream) {
+    (void)order; (void)stream;
+    if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
+    if (w->cfg.flags & REM2D_FLAG_RETILE) return c_fail(REM2D_E_INVALID, "set_order: the world deals its creatures itself (REM2D_FLAG_RETILE)");
+    return REM2D_OK;
+}
 /* launch options (include/rem2d.h REM2D_OPT_*): kept and handed back, nothing to steer on the CPU; same range checks */
 int rem2d_cpu_world_set_option(rem2d_cpu_world *w, int32_t key, int32_t value) {
     static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30};

@@ -527,3 +527,34 @@ def test_bench_population_exactly_as_benched_equals_the_oracle(need_gpu, oracle,
         checked += len(pick)
     assert checked >= 0.02 * 65536
     env.close()
+
+
+def test_rebalance_by_current_cost_keeps_population_order_results(need_gpu, oracle, rough_terrain):
+    """BatchedModular2D.rebalance (``rebalance_every`` env-steps; off by default): the creatures that used
+    every position iteration move to the front of their world's order.  What step() returns stays in POPULATION order and
+    equals the oracle bit for bit; the orders are permutations with the slow creatures first."""
+    import torch
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    from gym_rem2d_amd.env import BatchedModular2D
+    specs = synthetic.lsystem_specs(range(6000, 6000 + 4608), mutate_odd=True)
+    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS)
+    env.rebalance_every = 50
+    env.reset_specs(specs)
+    assert env._rebalance_steps == 50 and not (env._world_flags & _lib.FLAG_RETILE)
+    for _ in range(6):
+        reward, done = env.step(25)
+    torch.cuda.synchronize()
+    orders = [w._order[:w.n_envs].cpu().numpy() for w, _ in env.worlds if getattr(w, "_order", None) is not None]
+    assert orders and all(np.array_equal(np.sort(o), np.arange(len(o))) for o in orders)
+    assert any((o != np.arange(len(o))).any() for o in orders)        # some creature did move
+    ot = oracle_terrain(oracle, rough_terrain)
+    fit = env.fitness.cpu().numpy()
+    for (w, idx), part in zip(env.worlds, env._world_morph):
+        r = oracle.batch_run(ot, part.as_dict(), 150, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+        pop = idx.cpu().numpy()
+        assert np.array_equal(w.bodies(), r["bodies"])
+        assert np.array_equal(fit[pop], r["fitness"])
+        assert np.array_equal(reward.cpu().numpy()[pop], r["reward"].astype(np.float32))
+    assert int(env.errors().max()) == 0
+    env.close()

@@ -294,10 +294,13 @@ def test_full_size_chain8(gpu, oracle, flat_terrain):
     env.close()
 
 
+@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies"])
 @pytest.mark.parametrize("skip_frozen", [False, True])
-def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_frozen):
-    """REM2D_FLAG_RETILE: the position-iteration kernel deals the creatures to its wavefronts anew in every step (those that
-    used all 60 iterations first; the order comes out of atomics and differs from run to run).  Creatures are independent:
+def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_frozen, launch):
+    """REM2D_FLAG_RETILE: the creatures are dealt to the wavefronts anew in every step (those that used all 60 position
+    iterations first; the order comes out of atomics and differs from run to run) -- since round 4 for the velocity tiles as
+    for the position blocks (tile slot e = creature order[e]), in the one-launch form and in the two-launch forms alike.
+    Creatures are independent:
     poses, velocities, sleep state, reward, fitness and step counts equal the oracle's in every bit, also together with
     REM2D_FLAG_SKIP_FROZEN (wavefronts of pre whose creatures have all finished are skipped; post must leave exactly those
     creatures alone, whichever of its wavefronts they ride in)."""
@@ -307,7 +310,13 @@ def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_f
     morph = Morphology.from_specs(specs, 8)
     flags = _lib.FLAG_CONTINUOUS | _lib.FLAG_RETILE | (_lib.FLAG_SKIP_FROZEN if skip_frozen else 0)
     T = 420 if skip_frozen else 240     # (long enough for whole wavefronts of 8 creatures to have finished)
-    w, snaps = _run_gpu(gpu, morph, rough_terrain, [1, 59, T - 60], flags)
+    w = gpu(morph.n_envs, morph.lanes, flags, options={"fuse_velpost": 0} if launch == "two_launches" else None)
+    w.set_terrain(rough_terrain)
+    w.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    snaps = []
+    for c in [1, 59, T - 60]:
+        w.step(c)
+        snaps.append(w.bodies())
     ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
     assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
     assert int(w.view("err").max()) == 0
@@ -323,6 +332,40 @@ def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_f
         moved = w.view("steps").cpu().numpy() == T
         assert frozen.any() and np.array_equal(snaps[-1][moved], ref["bodies"][moved]) and (moved | frozen).all()
     w.close()
+
+
+@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies", "fused_step_kernel"])
+def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch):
+    """rem2d_world_set_order: slot e of the velocity tiles / position blocks handles creature order[e].  Any permutation --
+    here a random one, changed twice in mid-run, then back to the identity -- leaves poses, velocities, sleep state,
+    reward and fitness equal to the oracle's in every bit (creatures are independent), in the one-launch form, the two
+    launches, the 128-body tiles and (where the order has no meaning and is ignored) the fused step kernel."""
+    import torch
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    specs = [s for s in synthetic.lsystem_specs(range(400), mutate_odd=True) if 3 <= s.n_bodies <= 8]
+    morph = Morphology.from_specs(specs, 8)
+    opts = {"two_launches": {"fuse_velpost": 0}, "fused_step_kernel": {"pipeline": 0}}.get(launch)
+    w = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
+    w.set_terrain(rough_terrain)
+    w.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    g = torch.Generator().manual_seed(7)
+    T = 0
+    for chunk, order in ((40, torch.randperm(morph.n_envs, generator=g)), (80, torch.randperm(morph.n_envs, generator=g)),
+                         (60, torch.arange(morph.n_envs).flip(0)), (40, None)):
+        w.set_order(order)
+        w.step(chunk)
+        T += chunk
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+    assert np.array_equal(w.bodies(), ref["bodies"])
+    assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+    assert np.array_equal(w.view("reward").cpu().numpy(), ref["reward"].astype(np.float32))
+    assert int(w.view("err").max()) == 0 and int(w.view("toievents").sum()) > 0
+    w.close()
+    r = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS | _lib.FLAG_RETILE)
+    with pytest.raises(_lib.Rem2dError, match="RETILE"):     # a world that deals its creatures itself takes no host order
+        r.set_order(torch.arange(morph.n_envs))
+    r.close()
 
 
 def test_determinism(gpu, rough_terrain):

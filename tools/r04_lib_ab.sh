@@ -10,7 +10,7 @@ python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --min-ti
 for i in $(seq 1 $N); do
 for spec in "$@"; do
   v=${spec%%:*}; envs=""
-  if [ "$spec" != "$v" ]; then envs=${spec#*:}; fi
+  if [ "$spec" != "$v" ]; then envs=$(echo ${spec#*:} | tr ',' ' '); fi
   lib=${v%%+*}
   if [ $lib = base ]; then unset REM2D_LIB_PATH; else export REM2D_LIB_PATH=$PWD/build/ab/librem2d_$lib.so; fi
   env $envs timeout 600 python3 bench.py $ARGS > $O/b_${v}_$i.json 2>$O/err_${v}_$i.txt
