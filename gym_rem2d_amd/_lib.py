@@ -29,11 +29,11 @@ ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
 
 # launch options of a world (include/rem2d.h REM2D_OPT_*, rem2d_world_set_option): no result depends on them
-OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug")
+OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug", "rebalance")
 OPTION_ID = {n: i for i, n in enumerate(OPTIONS)}
 _ENV_OPTIONS = {"REM2D_PIPELINE": "pipeline", "REM2D_FUSE_VELPOST": "fuse_velpost", "REM2D_PRIO": "prio",
                 "REM2D_PRIO_T1": "prio_t1", "REM2D_PRIO_T2": "prio_t2", "REM2D_HEAVY_PER_WAVE": "heavy_per_wave",
-                "REM2D_V4_DBG": "debug"}
+                "REM2D_V4_DBG": "debug", "REM2D_REBALANCE_DEV": "rebalance"}
 
 
 def env_options():

@@ -130,6 +130,7 @@ struct rem2d_world {
     hipEvent_t evFork, evJoin; // fork / join edges of rem2d_groups_step (created on first use)
     uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
     int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
+    int64_t stepsQueued;          // env-steps queued so far (the cadence of REM2D_OPT_REBALANCE)
 };
 
 // Tile shape of rem2d_vel4_kernel (rem2d_world_set_tile_shape; rem2d_vel4.h explains the trade-off):
@@ -173,9 +174,11 @@ static int default_tile_creatures(const TileShape &shp, int lanes) {
 //   HEAVY_PER_WAVE bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel, 1..64 (one: a wavefront that
 //                  holds two runs the union of their code paths)
 //   DEBUG          diagnostic builds (-DREM2D_V4_PROBES) only: Vel4Args::dbg
-static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0};
-static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0};
-static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, WAVE, 1 << 30};
+//   REBALANCE      N > 0: every N env-steps the world's creature order is re-made on the device (rem2d_rebalance_kernel: the
+//                  creatures that used every position iteration first, a stable partition), 0 = off
+static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0, 0};
+static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0};
+static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, WAVE, 1 << 30, 1 << 20};
 
 static uint32_t __float_as_uint_host(float f) {
     uint32_t u;
@@ -254,6 +257,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->evFork = w->evJoin = nullptr;
     w->epoch = next_epoch();
     for (int k = 0; k < REM2D_OPT_COUNT; ++k) w->opt[k] = kOptDefault[k];
+    w->stepsQueued = 0;
     bind_state(w);
     w->S.scr = nullptr;
     hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
@@ -357,6 +361,13 @@ extern "C" int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value
     if (key < 0 || key >= REM2D_OPT_COUNT) return fail(REM2D_E_INVALID, "set_option: unknown option");
     if (value < kOptMin[key] || value > kOptMax[key] || (key == REM2D_OPT_PIPELINE && value != 0 && value != 3))
         return fail(REM2D_E_INVALID, "set_option: value out of range for this option");
+    if (key == REM2D_OPT_REBALANCE) {
+        if (value > 0 && (w->cfg.flags & REM2D_FLAG_RETILE))
+            return fail(REM2D_E_INVALID, "set_option: the world deals its creatures itself (REM2D_FLAG_RETILE)");
+        // the kernels go through State::order from now on (the identity until the first rebalance) / directly again
+        if (value > 0) w->S.flags |= REM2D_STATE_ORDERED;
+        else if (w->opt[key] > 0) w->S.flags &= ~REM2D_STATE_ORDERED;
+    }
     if (w->opt[key] != value) {
         w->opt[key] = value;
         w->epoch = next_epoch(); // (a captured replay of the old launch sequence is stale)
@@ -691,6 +702,8 @@ struct TilePlan {
     bool continuous;
     bool velpost; // one launch for the velocity iterations and post (rem2d_velpost_kernel)
     rem2d_world *w0;
+    rem2d_world *ws[REM2D_MAX_BATCH]; // the group's worlds (REM2D_OPT_REBALANCE runs per world)
+    int nw;
 };
 static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float dt, int vel_iters, int pos_iters) {
     Batch &B = P.B;
@@ -723,6 +736,8 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
     P.blocks = blocks;
     P.tiles = tiles;
     P.w0 = ws[0];
+    P.nw = n_worlds;
+    for (int i = 0; i < n_worlds; ++i) P.ws[i] = ws[i];
     // worlds planned for different tile shapes in one grid: the largest shape runs the smaller ones' tiles as well
     // (a tile within 64 joints fits any shape; one within 64 joints per phase pair fits the four-set shape)
     P.launchShape = 3;
@@ -762,6 +777,13 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     rem2d_world *w0 = P.w0;
     const dim3 grid(P.blocks), block(WAVE);
+    for (int i = 0; i < P.nw; ++i) { // REM2D_OPT_REBALANCE: a new creature order every N env-steps, made from the last step's state
+        rem2d_world *w = P.ws[i];
+        const int every = w->opt[REM2D_OPT_REBALANCE];
+        if (every > 0 && w->stepsQueued > 0 && w->stepsQueued % every == 0 && (w->S.flags & REM2D_STATE_ORDERED))
+            hipLaunchKernelGGL(rem2d_rebalance_kernel, dim3(1), dim3(REBALANCE_THREADS), 0, st, w->S, P.A.posIters);
+        w->stepsQueued += 1;
+    }
     const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                            hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
     // (a merged launch of shapes 1 and 4: rank picks 1, whose flexible kernel takes the statically planned tiles too)

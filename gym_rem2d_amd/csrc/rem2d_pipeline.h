@@ -413,6 +413,44 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
     BATCH_DISPATCH(post_only_body, psh)
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Creature order by current cost, made on the device (REM2D_OPT_REBALANCE): a STABLE partition of the world's creatures --
+// those that used every position iteration in the last step first, in their current static order, the others behind them
+// in theirs -- written to both halves of State::order (what rem2d_world_set_order would install).  One workgroup per world:
+// every thread counts the slow creatures of its contiguous chunk, the counts are scanned in LDS, every thread writes its
+// chunk's creatures to their places.  ~10 us for 16 384 creatures; launched every N env-steps in front of `pre`.
+// ---------------------------------------------------------------------------------------------------
+#define REBALANCE_THREADS 1024
+__global__ __launch_bounds__(REBALANCE_THREADS) void rem2d_rebalance_kernel(State S, int posIters) {
+    __shared__ int cnt[REBALANCE_THREADS];
+    const int n = (int)S.nEnvs, T = REBALANCE_THREADS, t = threadIdx.x;
+    const int per = (n + T - 1) / T;
+    const int lo = min(n, t * per), hi = min(n, lo + per);
+    int c = 0;
+    for (int e = lo; e < hi; ++e) {
+        const unsigned env = (unsigned)e;
+        c += EI(E_POSITERS) >= posIters ? 1 : 0;
+    }
+    cnt[t] = c;
+    __syncthreads();
+    for (int o = 1; o < T; o <<= 1) { // inclusive scan (Hillis-Steele)
+        const int v = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    const int nSlow = cnt[T - 1];
+    int ps = cnt[t] - c;        // slow creatures in front of this chunk
+    int pf = nSlow + (lo - ps); // place of this chunk's first fast creature
+    for (int e = lo; e < hi; ++e) {
+        const unsigned env = (unsigned)e;
+        const int pos = EI(E_POSITERS) >= posIters ? ps++ : pf++;
+        S.order[pos] = e;
+        S.order[S.Np + pos] = e;
+    }
+    for (int e = n + t; e < (int)S.Np; e += T) { S.order[e] = e; S.order[S.Np + e] = e; } // padding creatures keep their slots
+}
+
 // (Round 3 built "rest": post + the TOI solve of the wavefront's own bodies + the next step's pre in one launch, two
 // launches per step instead of four.  Bit-exact, but it needs the TOI solve's 256 VGPRs and was slower on every workload:
 // profiles/r03_fused_rest.txt.  Removed; post_body keeps the FUSED hook it used.)

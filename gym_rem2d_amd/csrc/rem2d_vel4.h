@@ -258,13 +258,16 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const int iters = A.velIters;
     const float h = A.dt, mu = friction;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (WAVE - lane));
-    if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // pre skipped these creatures: nothing to solve, nothing handed over
-        bool allFrozen = true;
+    if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // creatures pre left alone (it marks them 0x200): nothing to solve, nothing handed over
+        // (pre's own criterion -- its 64-lane wavefront in ARENA order held finished creatures only -- read back per creature:
+        // under a creature order a tile may hold finished creatures of wavefronts that pre did step)
+        bool allSkipped = true;
         for (int e = c0 + lane; e < c1; e += WAVE) {
             const unsigned env = retile ? (unsigned)S.order[e] : (unsigned)e;
-            allFrozen = allFrozen && EI(E_FROZEN) != 0;
+            const int m0 = __float_as_int(SW((unsigned)SCR_MISC_BASE * Lp + env * (unsigned)K, 0));
+            allSkipped = allSkipped && (m0 & 0x200) != 0;
         }
-        if (__all(allFrozen ? 1 : 0)) return;
+        if (__all(allSkipped ? 1 : 0)) return;
     }
 
 #pragma unroll

@@ -76,8 +76,7 @@ class BatchedModular2D:
     MAX_WORLD_LANES = 1 << 22   # rem2d_world_create refuses ~5 M lanes and more (32-bit lane offsets)
     BIG_POPULATION = 131072     # creatures per GPU from which the 128-lane tiles of the velocity kernel pay (round 4: 2 joint
                                 # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
-    RETILE_POPULATION = 98304   # ... from which dealing the creatures to the position kernel's wavefronts anew every step
-                                # (REM2D_FLAG_RETILE) pays: +4.4 % at 131 072, -5 % at 65 536 (profiles/r03_retile.txt)
+    REBALANCE_EVERY = 50        # env-steps between two re-orderings of a mixed population by current cost (see __init__)
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
@@ -106,13 +105,14 @@ class BatchedModular2D:
         self.groups, self.group_streams = [], []
         self._group_args = None
         self.use_graph = os.environ.get("REM2D_GRAPH", "0") == "1"   # replay every step call as a hipGraph
-        # Creature order by current cost (rebalance): every `rebalance_every` env-steps the creatures that used every position
-        # iteration in the last step are moved to the front of their world's order (a stable sort: the static schedule order
-        # survives within both classes), so that they share velocity tiles and position blocks.  0 (default): off -- measured
-        # +1.8 % on config 3, +2 % on the 131 072-creature generation against REM2D_FLAG_RETILE, but -3.7 % on config 4
-        # (profiles/r04_lane_fill_experiments.txt): not a policy yet.  REM2D_REBALANCE=<steps> switches it on (experiments).
-        self.rebalance_every = int(os.environ.get("REM2D_REBALANCE", "0"))
-        self._since_rebalance = 0
+        # Creature order by current cost: every `rebalance_every` env-steps the creatures that used every position iteration in
+        # the last step are moved to the front of their world's order (a stable partition: the static schedule order survives
+        # within both classes), so that they share velocity tiles and position blocks -- a tile costs what its most expensive
+        # creature costs.  Made on the device by the library itself (launch option `rebalance`, rem2d_rebalance_kernel: one
+        # small launch per world every N steps).  -1: automatic (50 for mixed populations: +3.3 % on config 3, +3 % on the
+        # 131 072-creature generation against REM2D_FLAG_RETILE, which it replaces as the policy; +0.5 % on config 4; -0.8 % at
+        # 1 M creatures), 0: off.  REM2D_REBALANCE overrides (experiments); rebalance() does the same from the host.
+        self.rebalance_every = int(os.environ.get("REM2D_REBALANCE", "-1"))
 
     def seed(self, seed=None):
         self._seed = seed
@@ -198,13 +198,15 @@ class BatchedModular2D:
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
                 shape = 4   # (128-lane tiles with the static phase -> set map: nothing to rotate in a uniform population)
         self._tile_shape_used = shape
-        retile = os.environ.get("REM2D_RETILE")
-        retile = (n_envs >= self.RETILE_POPULATION and not all(_uniform(m) for m, _ in batches)) if retile is None else retile == "1"
+        # REM2D_FLAG_RETILE (the position kernel deals the creatures anew in every step, in arrival order) was round 3's policy
+        # for >= 98 304 creatures; the stable re-ordering every 50 steps does better there and also pays at 65 536
+        # (profiles/r04_lane_fill_experiments.txt), so the flag is an experiment override now (REM2D_RETILE=1)
+        retile = os.environ.get("REM2D_RETILE") == "1"
         self._world_flags = (self.flags | _lib.FLAG_RETILE) if retile else (self.flags & ~_lib.FLAG_RETILE)
-        self._rebalance_steps = max(0, self.rebalance_every)
-        if retile:
-            self._rebalance_steps = 0   # (the position kernel deals the creatures itself)
-        self._since_rebalance = 0
+        every = self.rebalance_every
+        if every < 0:
+            every = self.REBALANCE_EVERY if (n_envs >= 4096 and not all(_uniform(m) for m, _ in batches)) else 0
+        self._rebalance_steps = 0 if retile else every
         self.groups = [[] for _ in range(groups)]
         for morph, idx in batches:
             idx = np.asarray(idx, dtype=np.int64)
@@ -227,7 +229,8 @@ class BatchedModular2D:
                     pieces.append((g, mem[lo:lo + per]))
             for g, mem in pieces:
                 part = morph if len(mem) == morph.n_envs else morph.take(mem)
-                w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide)
+                w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide,
+                                 options={"rebalance": self._rebalance_steps} if self._rebalance_steps > 0 else None)
                 w.set_terrain(self._terrain())
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
@@ -303,22 +306,17 @@ class BatchedModular2D:
                     w.step(n_steps)
             for st in self.streams:
                 cur.wait_stream(st)
-        if self._rebalance_steps > 0:
-            self._since_rebalance += int(n_steps)
-            if self._since_rebalance >= self._rebalance_steps:
-                self.rebalance()
         if len(self.worlds) == 1 and not self._compacted:
             w = self.worlds[0][0]
             return w.view("reward"), w.view("done") != 0
         return self._reward, self._done   # written by the step's own kernels (set_outputs in _upload)
 
     def rebalance(self, pos_iters=60):
-        """Give every world a creature order by CURRENT cost (rem2d_world_set_order): the creatures that used all `pos_iters`
-        position iterations in the last step -- a joint at its limit pressed against the ground; the same creatures for many
-        steps -- go to the front, in their static order, the others follow in theirs.  A velocity tile / position block costs
-        what its most expensive creature costs, so the expensive ones should share wavefronts.  A few small torch kernels
-        per world, queued on the caller's stream like the steps; no effect on any result."""
-        self._since_rebalance = 0
+        """The host-side form of the `rebalance` launch option (which does the same on the device every N steps): give every
+        world a creature order by CURRENT cost through rem2d_world_set_order -- the creatures that used all `pos_iters`
+        position iterations in the last step (a joint at its limit pressed against the ground; the same creatures for many
+        steps) go to the front, in their static order, the others follow in theirs.  A few small torch kernels per world,
+        queued on the caller's stream like the steps; no effect on any result."""
         for wi, (w, _) in enumerate(self.worlds):
             if wi in self._inactive or (w.flags & _lib.FLAG_RETILE) or w.n_envs < 2 * (64 // min(64, w.lanes)):
                 continue
@@ -378,7 +376,8 @@ class BatchedModular2D:
                 self._inactive.update(wis)
                 continue
             part = Morphology.concat([self._world_morph[wi].take(k.cpu().numpy()) for wi, k in zip(wis, keeps) if k.numel()])
-            nw = BatchedWorld(n_keep, lanes, self._world_flags, self.device, wide=self.wide)
+            nw = BatchedWorld(n_keep, lanes, self._world_flags, self.device, wide=self.wide,
+                              options={"rebalance": self._rebalance_steps} if self._rebalance_steps > 0 else None)
             nw.set_terrain(self._terrain())
             for name in _lib.FIELDS:
                 dst = nw.view(name)

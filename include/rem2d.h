@@ -225,10 +225,13 @@ int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream
  *   REM2D_OPT_PRIO_T1 / _T2   slot-cost thresholds (7 per tick + 10 per contact sub-slot) for priority 1 / 3, default 60 / 75
  *   REM2D_OPT_HEAVY_PER_WAVE  bodies of the TOI work list per wavefront, 1..64, default 1
  *   REM2D_OPT_DEBUG           diagnostic builds only (-DREM2D_V4_PROBES), default 0
+ *   REM2D_OPT_REBALANCE       N > 0: every N env-steps the library re-makes the world's creature order on the device (what
+ *                             rem2d_world_set_order installs from the host: the creatures that used every position iteration in
+ *                             the last step first, a stable partition); 0 (default) off.  Refused with REM2D_FLAG_RETILE
  * Returns REM2D_E_INVALID for an unknown key or a value outside the option's range. */
 enum {
     REM2D_OPT_PIPELINE = 0, REM2D_OPT_FUSE_VELPOST, REM2D_OPT_PRIO, REM2D_OPT_PRIO_T1, REM2D_OPT_PRIO_T2,
-    REM2D_OPT_HEAVY_PER_WAVE, REM2D_OPT_DEBUG, REM2D_OPT_COUNT
+    REM2D_OPT_HEAVY_PER_WAVE, REM2D_OPT_DEBUG, REM2D_OPT_REBALANCE, REM2D_OPT_COUNT
 };
 int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value);
 int rem2d_world_get_option(const rem2d_world *w, int32_t key, int32_t *value);

@@ -121,7 +121,7 @@ int rem2d_cpu_world_create(const rem2d_world_cfg *cfg, void *state_host, size_t 
     w->slotBody = (int8_t *)malloc((size_t)cfg->n_envs * cfg->lanes);
     if (!w->worlds || !w->slotBody) { free(w->worlds); free(w->slotBody); free(w); return c_fail(REM2D_E_NOMEM, "out of memory"); }
     memset(w->arena, 0, L.total);
-    { static const int32_t def[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0}; memcpy(w->opt, def, sizeof def); }
+    { static const int32_t def[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0, 0}; memcpy(w->opt, def, sizeof def); }
     *out = w;
     return REM2D_OK;
 }
@@ -178,7 +178,7 @@ int rem2d_cpu_world_set_order(rem2d_cpu_world *w, const int32_t *order, void *st
 }
 /* launch options (include/rem2d.h REM2D_OPT_*): kept and handed back, nothing to steer on the CPU; same range checks */
 int rem2d_cpu_world_set_option(rem2d_cpu_world *w, int32_t key, int32_t value) {
-    static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30};
+    static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30, 1 << 20};
     if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
     if (key < 0 || key >= REM2D_OPT_COUNT) return c_fail(REM2D_E_INVALID, "set_option: unknown option");
     if (value < lo[key] || value > hi[key] || (key == REM2D_OPT_PIPELINE && value != 0 && value != 3))

@@ -530,20 +530,23 @@ def test_bench_population_exactly_as_benched_equals_the_oracle(need_gpu, oracle,
 
 
 def test_rebalance_by_current_cost_keeps_population_order_results(need_gpu, oracle, rough_terrain):
-    """BatchedModular2D.rebalance (``rebalance_every`` env-steps; off by default): the creatures that used
-    every position iteration move to the front of their world's order.  What step() returns stays in POPULATION order and
-    equals the oracle bit for bit; the orders are permutations with the slow creatures first."""
+    """Mixed populations re-order their creatures by current cost every REBALANCE_EVERY env-steps (launch option `rebalance`:
+    the creatures that used every position iteration move to the front of their world's order, on the device); the host-side
+    BatchedModular2D.rebalance() installs the same kind of order through rem2d_world_set_order.  What step() returns stays
+    in POPULATION order and equals the oracle bit for bit; the host-made orders are permutations with the slow creatures
+    first."""
     import torch
     from gym_rem2d_amd import _lib, synthetic
-    from gym_rem2d_amd.compiler import Morphology
     from gym_rem2d_amd.env import BatchedModular2D
     specs = synthetic.lsystem_specs(range(6000, 6000 + 4608), mutate_odd=True)
     env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS)
-    env.rebalance_every = 50
     env.reset_specs(specs)
-    assert env._rebalance_steps == 50 and not (env._world_flags & _lib.FLAG_RETILE)
-    for _ in range(6):
+    assert env._rebalance_steps == env.REBALANCE_EVERY and not (env._world_flags & _lib.FLAG_RETILE)
+    assert all(w.get_option("rebalance") == env.REBALANCE_EVERY for w, _ in env.worlds)
+    for k in range(6):
         reward, done = env.step(25)
+        if k == 3:
+            env.rebalance()                  # (the host-side form on top, in mid-run)
     torch.cuda.synchronize()
     orders = [w._order[:w.n_envs].cpu().numpy() for w, _ in env.worlds if getattr(w, "_order", None) is not None]
     assert orders and all(np.array_equal(np.sort(o), np.arange(len(o))) for o in orders)
@@ -558,3 +561,7 @@ def test_rebalance_by_current_cost_keeps_population_order_results(need_gpu, orac
         assert np.array_equal(reward.cpu().numpy()[pop], r["reward"].astype(np.float32))
     assert int(env.errors().max()) == 0
     env.close()
+    uni = BatchedModular2D(flat=True, flags=_lib.FLAG_CONTINUOUS)      # fixed-morphology populations have nothing to re-order
+    uni.reset_morphology(synthetic.chain_population(8192, 4, "left"))
+    assert uni._rebalance_steps == 0 and uni.worlds[0][0].get_option("rebalance") == 0
+    uni.close()

@@ -365,7 +365,20 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     r = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS | _lib.FLAG_RETILE)
     with pytest.raises(_lib.Rem2dError, match="RETILE"):     # a world that deals its creatures itself takes no host order
         r.set_order(torch.arange(morph.n_envs))
+    with pytest.raises(_lib.Rem2dError, match="RETILE"):
+        r.set_option("rebalance", 10)
     r.close()
+    # the same order made by the library itself every few steps (REM2D_OPT_REBALANCE: a stable partition on the device, the
+    # creatures that used every position iteration first)
+    opts = dict(opts or {}, rebalance=7)
+    d = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
+    d.set_terrain(rough_terrain)
+    d.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    for chunk in (40, 80, 60, 40):
+        d.step(chunk)
+    assert np.array_equal(d.bodies(), ref["bodies"]) and np.array_equal(d.view("fitness").cpu().numpy(), ref["fitness"])
+    assert int(d.view("err").max()) == 0
+    d.close()
 
 
 def test_determinism(gpu, rough_terrain):
@@ -477,7 +490,7 @@ def test_option_argument_errors(gpu):
     from gym_rem2d_amd import _lib
     w = gpu(4, 4, 0)
     L = _lib.lib()
-    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 1, 5, 60, 75, 1, 0]     # the documented defaults
+    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 1, 5, 60, 75, 1, 0, 0]     # the documented defaults
     for key, bad in ((0, 1), (0, 2), (1, 2), (5, 0), (5, 65), (2, -1), (99, 0), (-1, 0)):
         assert L.rem2d_world_set_option(w.h, key, bad) == -1, (key, bad)
     assert b"option" in L.rem2d_last_error()
@@ -643,7 +656,7 @@ def test_full_size_config5_generation_share(gpu, oracle, rough_terrain):
 
 def test_tile_shape_per_world_and_mixed_in_one_launch(gpu, oracle, rough_terrain):
     """rem2d_world_set_tile_shape: the launch shape of the velocity kernel is a property of the world (the env picks
-    the 256-lane tiles for populations beyond ~100 000 creatures).  The three shapes give the oracle's bits, also when
+    the 128-lane tiles for populations beyond ~130 000 creatures).  The five shapes give the oracle's bits, also when
     worlds planned for different shapes share one merged launch (rem2d_worlds_step)."""
     import ctypes as C
     from gym_rem2d_amd import _lib
@@ -652,10 +665,10 @@ def test_tile_shape_per_world_and_mixed_in_one_launch(gpu, oracle, rough_terrain
     T = 90
     refs = [oracle.batch_run(oracle_terrain(oracle, rough_terrain), m.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
             for m in morphs]
-    for shapes in ((0, 0, 0), (1, 1, 1), (3, 3, 3), (0, 3, 1), (3, 1, 0)):
+    for shapes in ((0, 0, 0), (1, 1, 1), (3, 3, 3), (0, 3, 1), (3, 1, 0), (2, 2, 2), (4, 4, 4), (4, 1, 3), (2, 4, 1)):
         ws = []
         for m, sh in zip(morphs, shapes):
-            if m.lanes > (256, 128, 0, 64)[sh]:
+            if m.lanes > (256, 128, 192, 64, 128)[sh]:
                 sh = 0
             w = gpu(m.n_envs, m.lanes, flags=_lib.FLAG_CONTINUOUS)
             w.set_terrain(rough_terrain)
@@ -672,5 +685,5 @@ def test_tile_shape_per_world_and_mixed_in_one_launch(gpu, oracle, rough_terrain
             w.close()
     w = gpu(morphs[0].n_envs, morphs[0].lanes)
     with pytest.raises(_lib.Rem2dError, match="tile shape"):
-        _lib.check(_lib.lib().rem2d_world_set_tile_shape(w.h, 2))
+        _lib.check(_lib.lib().rem2d_world_set_tile_shape(w.h, 5))
     w.close()
