@@ -414,39 +414,72 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Creature order by current cost, made on the device (REM2D_OPT_REBALANCE): a STABLE partition of the world's creatures --
-// those that used every position iteration in the last step first, in their current static order, the others behind them
-// in theirs -- written to both halves of State::order (what rem2d_world_set_order would install).  One workgroup per world:
-// every thread counts the slow creatures of its contiguous chunk, the counts are scanned in LDS, every thread writes its
-// chunk's creatures to their places.  ~10 us for 16 384 creatures; launched every N env-steps in front of `pre`.
+// Creature order by current cost, made on the device (REM2D_OPT_REBALANCE): a STABLE counting sort of the world's creatures
+// by cost class -- those that used every position iteration in the last step first, in their static order, the others behind
+// them in theirs -- written to both halves of State::order (what rem2d_world_set_order would install).  One workgroup per
+// world: every thread counts the classes of its contiguous chunk, the counts are scanned in LDS, every thread writes its
+// chunk's creatures to their places; launched every N env-steps in front of `pre`.
 // ---------------------------------------------------------------------------------------------------
-#define REBALANCE_THREADS 1024
+// (One wavefront: it starts as soon as any wavefront slot is free, and the work is a few dozen microseconds either way --
+// 64 / 256 / 1 024 threads measured the same on every workload, profiles/r04_lane_fill_experiments.txt.)
+#ifndef REBALANCE_THREADS
+#define REBALANCE_THREADS 64
+#endif
+#ifndef REBALANCE_CLASSES
+#define REBALANCE_CLASSES 2
+#endif
+// cost class of a creature from the position iterations of its last step: 0 = used all of them (the long blocks), ...
+DEV int rebalance_class(int positers, int posIters) {
+#if REBALANCE_CLASSES == 2
+    return positers >= posIters ? 0 : 1;
+#elif REBALANCE_CLASSES == 3
+    return positers >= posIters ? 0 : (positers >= 3 ? 1 : 2);
+#else
+    return positers >= posIters ? 0 : (positers >= 8 ? 1 : (positers >= 3 ? 2 : 3));
+#endif
+}
 __global__ __launch_bounds__(REBALANCE_THREADS) void rem2d_rebalance_kernel(State S, int posIters) {
-    __shared__ int cnt[REBALANCE_THREADS];
+    __shared__ int cnt[REBALANCE_CLASSES][REBALANCE_THREADS];
     const int n = (int)S.nEnvs, T = REBALANCE_THREADS, t = threadIdx.x;
     const int per = (n + T - 1) / T;
     const int lo = min(n, t * per), hi = min(n, lo + per);
-    int c = 0;
+    int c[REBALANCE_CLASSES];
+#pragma unroll
+    for (int k = 0; k < REBALANCE_CLASSES; ++k) c[k] = 0;
     for (int e = lo; e < hi; ++e) {
         const unsigned env = (unsigned)e;
-        c += EI(E_POSITERS) >= posIters ? 1 : 0;
+        const int cls = rebalance_class(EI(E_POSITERS), posIters);
+#pragma unroll
+        for (int k = 0; k < REBALANCE_CLASSES; ++k) c[k] += cls == k ? 1 : 0;
     }
-    cnt[t] = c;
+#pragma unroll
+    for (int k = 0; k < REBALANCE_CLASSES; ++k) cnt[k][t] = c[k];
     __syncthreads();
-    for (int o = 1; o < T; o <<= 1) { // inclusive scan (Hillis-Steele)
-        const int v = t >= o ? cnt[t - o] : 0;
+    for (int o = 1; o < T; o <<= 1) { // inclusive scans (Hillis-Steele), one per class
+        int v[REBALANCE_CLASSES];
+#pragma unroll
+        for (int k = 0; k < REBALANCE_CLASSES; ++k) v[k] = t >= o ? cnt[k][t - o] : 0;
         __syncthreads();
-        cnt[t] += v;
+#pragma unroll
+        for (int k = 0; k < REBALANCE_CLASSES; ++k) cnt[k][t] += v[k];
         __syncthreads();
     }
-    const int nSlow = cnt[T - 1];
-    int ps = cnt[t] - c;        // slow creatures in front of this chunk
-    int pf = nSlow + (lo - ps); // place of this chunk's first fast creature
+    // a stable counting sort: class k starts behind all creatures of the classes before it; inside a class, chunk by chunk
+    int pos[REBALANCE_CLASSES], base = 0;
+#pragma unroll
+    for (int k = 0; k < REBALANCE_CLASSES; ++k) {
+        pos[k] = base + cnt[k][t] - c[k];
+        base += cnt[k][T - 1];
+    }
     for (int e = lo; e < hi; ++e) {
         const unsigned env = (unsigned)e;
-        const int pos = EI(E_POSITERS) >= posIters ? ps++ : pf++;
-        S.order[pos] = e;
-        S.order[S.Np + pos] = e;
+        const int cls = rebalance_class(EI(E_POSITERS), posIters);
+        int p = 0;
+#pragma unroll
+        for (int k = 0; k < REBALANCE_CLASSES; ++k)
+            if (cls == k) p = pos[k]++;
+        S.order[p] = e;
+        S.order[S.Np + p] = e;
     }
     for (int e = n + t; e < (int)S.Np; e += T) { S.order[e] = e; S.order[S.Np + e] = e; } // padding creatures keep their slots
 }
