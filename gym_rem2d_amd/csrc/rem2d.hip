@@ -772,7 +772,7 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 #define REM2D_SHAPE1_WPS 4 // wavefronts per SIMD the 128-body tile shape is compiled for
 #endif
 #ifndef REM2D_SHAPE1_PAIR
-#define REM2D_SHAPE1_PAIR true
+#define REM2D_SHAPE1_PAIR false // (lane-pair contact solves: a 128-body tile's manifolds rarely fit 32 lanes; without them 3 VGPR spills instead of 7, +2.7 % at 393 216 creatures)
 #endif
 static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     rem2d_world *w0 = P.w0;

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 DEV int rebalance_class(int positers, int posIters) {
 #if REBALANCE_CLASSES == 2
     return positers >= posIters ? 0 : 1;
+
 #elif REBALANCE_CLASSES == 3
     return positers >= posIters ? 0 : (positers >= 3 ? 1 : 2);
 #else
@@ -446,9 +447,12 @@ __global__ __launch_bounds__(REBALANCE_THREADS) void rem2d_rebalance_kernel(Stat
     int c[REBALANCE_CLASSES];
 #pragma unroll
     for (int k = 0; k < REBALANCE_CLASSES; ++k) c[k] = 0;
-    for (int e = lo; e < hi; ++e) {
+    auto key_of = [&](int e) -> int {
         const unsigned env = (unsigned)e;
-        const int cls = rebalance_class(EI(E_POSITERS), posIters);
+        return EI(E_POSITERS);
+    };
+    for (int e = lo; e < hi; ++e) {
+        const int cls = rebalance_class(key_of(e), posIters);
 #pragma unroll
         for (int k = 0; k < REBALANCE_CLASSES; ++k) c[k] += cls == k ? 1 : 0;
     }
@@ -472,8 +476,7 @@ __global__ __launch_bounds__(REBALANCE_THREADS) void rem2d_rebalance_kernel(Stat
         base += cnt[k][T - 1];
     }
     for (int e = lo; e < hi; ++e) {
-        const unsigned env = (unsigned)e;
-        const int cls = rebalance_class(EI(E_POSITERS), posIters);
+        const int cls = rebalance_class(key_of(e), posIters);
         int p = 0;
 #pragma unroll
         for (int k = 0; k < REBALANCE_CLASSES; ++k)

@@ -20,6 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=20000)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rebalance", type=int, default=37,
+                    help="launch option `rebalance`: the library re-makes every world's creature order on the device every N env-steps "
+                         "(0 = off); the default is an odd cadence so that the orders change at many different step numbers")
     args = ap.parse_args()
     import bench
     from gym_rem2d_amd import make_terrain
@@ -44,7 +47,7 @@ def main():
         t0 = time.time()
         stats = dict(toi_events=0, max_pairs=0, max_positers=0, creatures=0, bodies=0)
         for m, idx in batches:
-            w = BatchedWorld(m.n_envs, m.lanes, 1)
+            w = BatchedWorld(m.n_envs, m.lanes, 1, options={"rebalance": args.rebalance} if args.rebalance > 0 else None)
             w.set_terrain(terrain)
             w.reset(m)
             w.step(args.steps)
@@ -61,7 +64,8 @@ def main():
                 bad += int((~(got == ref["bodies"]).all(axis=(1, 2))).sum())
             stats["creatures"] += m.n_envs
             stats["bodies"] += int(m.n_bodies.sum())
-        report.append(dict(case=name, steps=args.steps, mismatching_creatures=bad, seconds=round(time.time() - t0, 1), **stats))
+        report.append(dict(case=name, steps=args.steps, rebalance_every=args.rebalance, mismatching_creatures=bad,
+                           seconds=round(time.time() - t0, 1), **stats))
         print(json.dumps(report[-1]), flush=True)
     ok = all(r["mismatching_creatures"] == 0 for r in report)
     print("SOAK " + ("OK" if ok else "MISMATCH"))
