@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=20000)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--encodings", action="store_true", help="also network-encoded (hardcore track) and direct-encoding populations")
     ap.add_argument("--rebalance", type=int, default=37,
                     help="launch option `rebalance`: the library re-makes every world's creature order on the device every N env-steps "
                          "(0 = off); the default is an odd cadence so that the orders change at many different step numbers")
@@ -32,13 +33,29 @@ def main():
     O.build()
     rng = np.random.default_rng(2026)
     report = []
-    for name, terrain, max_modules, mutate in (("lsystem/rough", make_terrain(4), 15, 4),
-                                               ("lsystem40/hardcore", make_terrain(4, hardcore=True), 40, 6),
-                                               ("lsystem/flat", make_terrain(4, flat=True), 20, 0)):
-        pop = LSystemPopulation.random(args.n if max_modules < 40 else args.n // 4, rng, max_modules=max_modules)
-        for _ in range(mutate):
-            pop.mutate(0.3, 0.3, 0.2, rng)
-        batches = pop.compile()
+    cases = [("lsystem/rough", make_terrain(4), 15, 4), ("lsystem40/hardcore", make_terrain(4, hardcore=True), 40, 6),
+             ("lsystem/flat", make_terrain(4, flat=True), 20, 0)]
+    if args.encodings:
+        # the other two encodings: network-encoded creatures (config 4's generator, seeds from 10^6) on the hardcore track and
+        # direct-encoding creatures (config 1's) on the default terrain
+        cases += [("network/hardcore", make_terrain(4, hardcore=True), -1, 0), ("direct/rough", make_terrain(4), -2, 0)]
+    for name, terrain, max_modules, mutate in cases:
+        if max_modules == -1:
+            from gym_rem2d_amd import synthetic
+            batches = [(m, idx.tolist()) for m, idx in synthetic.cppn_batches_native(range(10 ** 6, 10 ** 6 + args.n // 2), n_proc=1)]
+        elif max_modules == -2:
+            from gym_rem2d_amd import synthetic
+            from gym_rem2d_amd.compiler import lanes_for
+            specs = synthetic.direct_specs(range(10 ** 6, 10 ** 6 + args.n // 8))
+            groups = {}
+            for e, sp in enumerate(specs):
+                groups.setdefault(lanes_for(sp.n_bodies), []).append(e)
+            batches = [(Morphology.from_specs([specs[e] for e in groups[k]], k), groups[k]) for k in sorted(groups)]
+        else:
+            pop = LSystemPopulation.random(args.n if max_modules < 40 else args.n // 4, rng, max_modules=max_modules)
+            for _ in range(mutate):
+                pop.mutate(0.3, 0.3, 0.2, rng)
+            batches = pop.compile()
         import torch
         from gym_rem2d_amd.world import BatchedWorld
         xs, ys, polys = terrain.f32()
