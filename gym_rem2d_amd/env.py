@@ -321,7 +321,7 @@ class BatchedModular2D:
             if wi in self._inactive or (w.flags & _lib.FLAG_RETILE) or w.n_envs < 2 * (64 // min(64, w.lanes)):
                 continue
             slow = w.view("positers") >= pos_iters
-            w.set_order(torch.sort((~slow).to(torch.uint8), stable=True).indices)
+            w.set_order(torch.sort((~slow).to(torch.uint8), stable=True).indices, check=False)   # (a sort's indices)
 
     def launch_info(self):
         """(tile shape, velocity tiles and position iterations in one launch?) of the first step group -- the library's own

@@ -49,16 +49,21 @@ class BatchedWorld:
         for name, value in dict(_lib.env_options(), **(options or {})).items():
             self.set_option(name, value)
 
-    def set_order(self, order):
+    def set_order(self, order, check=True):
         """Install a creature order (rem2d_world_set_order): slot e of the velocity tiles / position blocks handles creature
-        order[e].  order: int tensor [n_envs] -- a permutation of the creatures -- on any device, or None for the identity.
-        Padding slots keep themselves.  A launch shape: results do not depend on it."""
+        order[e].  order: int tensor [n_envs] -- a permutation of the creatures (verified unless check=False) -- on any
+        device, or None for the identity.  Padding slots keep themselves.  A launch shape: results do not depend on it."""
         if order is None:
             self._order = None
             self._check(self.L.rem2d_world_set_order(self.h, None, self._stream()))
             return
+        order = order.to(device=self.device, dtype=torch.int64)
+        if check:   # the library trusts the array (a duplicate would make two slots step one creature): verify here
+            if order.numel() != self.n_envs or not bool(torch.equal(torch.sort(order).values,
+                                                                       torch.arange(self.n_envs, device=self.device))):
+                raise ValueError("set_order: `order` must be a permutation of range(n_envs)")
         full = torch.arange(self.n_envs_padded, dtype=torch.int32, device=self.device)
-        full[:self.n_envs] = order.to(device=self.device, dtype=torch.int32)
+        full[:self.n_envs] = order.to(torch.int32)
         self._order = full   # (kept alive until the asynchronous copy has run)
         self._check(self.L.rem2d_world_set_order(self.h, full.data_ptr(), self._stream()))
 

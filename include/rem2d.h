@@ -47,11 +47,12 @@ enum {
  * > ENV_LENGTH).  With this flag a wavefront whose creatures are ALL in that state (REM2D_F_FROZEN) is not
  * stepped any more; fitness is unaffected, the bodies of such creatures simply stop where they were. */
 #define REM2D_FLAG_SKIP_FROZEN 8u
-/* Launch shape, no effect on results: the position-iteration kernel deals the creatures to its wavefronts anew in every
+/* Launch shape, no effect on results: the position-iteration kernel deals the creatures to the wavefronts anew in every
  * step -- those that used all 60 position iterations in the last step (the same ~12 % from step to step) share wavefronts
- * instead of keeping 70 % of them busy for 60 iterations.  A third fewer wave-instructions in that kernel but a longer
- * slowest wavefront: pays where instruction issue limits the step (>~100 000 creatures per GPU), costs where the chain
- * of kernels does.  gym_rem2d_amd.env.BatchedModular2D sets it by population size. */
+ * instead of keeping 70 % of them busy for 60 iterations; since ABI v8 the velocity tiles go through the same creature order
+ * (tile slot e = creature order[e]), so the one-launch form works with it.  The dealing is by atomics, i.e. in arrival order:
+ * it destroys the static schedule order inside the tiles, which is why round 4's policy is the STABLE re-ordering of
+ * REM2D_OPT_REBALANCE / rem2d_world_set_order instead (gym_rem2d_amd.env.BatchedModular2D); the flag stays as an option. */
 #define REM2D_FLAG_RETILE 16u
 
 #define REM2D_MAX_LANES 64

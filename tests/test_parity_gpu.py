@@ -361,6 +361,10 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
     assert np.array_equal(w.view("reward").cpu().numpy(), ref["reward"].astype(np.float32))
     assert int(w.view("err").max()) == 0 and int(w.view("toievents").sum()) > 0
+    with pytest.raises(ValueError, match="permutation"):        # the host wrapper refuses what is not a permutation
+        w.set_order(torch.zeros(morph.n_envs, dtype=torch.long))
+    with pytest.raises(ValueError, match="permutation"):
+        w.set_order(torch.arange(morph.n_envs - 1))
     w.close()
     r = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS | _lib.FLAG_RETILE)
     with pytest.raises(_lib.Rem2dError, match="RETILE"):     # a world that deals its creatures itself takes no host order
