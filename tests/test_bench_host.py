@@ -114,3 +114,19 @@ def test_bench_population_is_the_seeded_python_population(tmp_path, monkeypatch)
                     assert np.array_equal(ref.arrays[k], m.arrays[k]), (workload, m.lanes, k)
             assert "seeds %d..%d" % (first, first + n - 1) in desc
     assert sorted(os.listdir(tmp_path)) == ["rem2d_bench_genomes_cppn_hardcore_300_50.npz", "rem2d_bench_genomes_lsystem_700_4000.npz"]
+
+
+def test_cpu_baseline_sample_is_capped_by_host_memory(monkeypatch, oracle):
+    """The oracle worlds of the CPU-baseline window are alive at once (~0.6 MB each): the sample is capped by a quarter of the
+    memory the cgroup / the machine still has, so that a small container does not run out of memory after the GPU result is
+    in."""
+    import bench
+    from gym_rem2d_amd import make_terrain, synthetic
+    from gym_rem2d_amd.compiler import Morphology
+    b = bench.host_memory_budget()
+    assert 0 < b <= 4 << 30
+    monkeypatch.setattr(bench, "host_memory_budget", lambda: 70 * bench.ORACLE_WORLD_BYTES)
+    m = Morphology.from_specs(synthetic.lsystem_specs(range(400)), 16)
+    cb = bench.cpu_baseline([m], make_terrain(4, flat=True), 1, settle=5, window=20, budget_s=2.0)
+    n = int(cb["sample"].split(" creatures")[0])
+    assert 32 <= n <= 70, cb["sample"]
