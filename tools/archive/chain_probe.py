@@ -4,7 +4,7 @@ tile is a 64-lane block): per 64-lane block of config 3's lane buckets, the time
 and in the position kernel of the same step (s_memrealtime, 10 ns) -- what a launch per phase costs (the sum of the two
 maxima) against what one launch for both would (the maximum of the sums)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

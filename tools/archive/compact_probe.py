@@ -2,7 +2,7 @@
 """Scratch probe (GPU box): wall time of an evaluate() episode of a random L-system population with and without moving
 the survivors into smaller worlds (BatchedModular2D.compact), and the step time along the episode."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 from gym_rem2d_amd import _lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scratch (GPU box): which creatures of an array population differ from the oracle, in which bucket / tile."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 from gym_rem2d_amd import make_terrain

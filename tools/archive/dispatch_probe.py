@@ -3,7 +3,7 @@
 rem2d_vel4_kernel launch start and end (s_memrealtime, 100 MHz, chip-wide)?  One step group of config 3 in one merged
 launch, as bench.py steps it."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import ctypes as C
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """Scratch probe (GPU box): env-steps/s of BatchedModular2D.step without per-kernel timing (so that the library replays
 its kernel sequence as a hipGraph; REM2D_GRAPH=0 switches that off).  usage: graph_probe.py workload [steps_per_call]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 import bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scratch probe (GPU box): cost split of the step kernel by ablating iteration counts via step_ex."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

@@ -3,7 +3,7 @@
 one lane bucket of config 3 (argument: lanes, default 16; discrete stepping so that the TOI kernel leaves the counters alone)
 -- ticks, contact sections, cycles per section, and what their creatures look like."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

@@ -2,7 +2,7 @@
 """Scratch probe (GPU box): s_memtime split of the position solver's tick loop (contact section / joint section /
 verdict) over the wavefronts that iterate (nearly) to the end.  Needs a -DREM2D_POS_STAMPS build via REM2D_LIB_PATH."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import ctypes as C
 import numpy as np
 import torch

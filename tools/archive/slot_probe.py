@@ -2,7 +2,7 @@
 """Scratch probe (GPU box): how many contact-solve bodies a wave executes per velocity iteration
 (per phase of the pipeline period), from a settled state of the largest lane bucket."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

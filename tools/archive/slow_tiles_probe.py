@@ -2,7 +2,7 @@
 """Scratch probe (GPU box, -DREM2D_V4_PROBES build via REM2D_LIB_PATH, REM2D_V4_DBG=32): the slowest tiles of the velocity
 kernel in one lane bucket of config 3 (argument: lanes, default 8) -- ticks, contact sub-slots, cycles per slot, and what their creatures look like."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

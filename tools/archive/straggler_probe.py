@@ -3,7 +3,7 @@
 velocity loop (s_memtime) next to the position iterations its creatures used -- are the slow wavefronts of the velocity
 kernel and of the position kernel the same ones?  (What a vel+post kernel without the barrier in between could gain.)"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

@@ -2,7 +2,7 @@
 """Scratch probe (GPU box): how much TOI work a settled population does per step -- bodies that reach the heavy
 kernel (work-list length is not exposed, so: bodies whose pair flags carry a computed TOI) and TOI events."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench

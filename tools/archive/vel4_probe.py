@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scratch probe (GPU box): device time of rem2d_vel4_kernel per lane bucket alone (HIP events around the kernel)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 import bench
