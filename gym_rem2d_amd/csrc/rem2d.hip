@@ -781,7 +781,11 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
         rem2d_world *w = P.ws[i];
         const int every = w->opt[REM2D_OPT_REBALANCE];
         if (every > 0 && w->stepsQueued > 0 && w->stepsQueued % every == 0 && (w->S.flags & REM2D_STATE_ORDERED))
-            hipLaunchKernelGGL(rem2d_rebalance_kernel, dim3(1), dim3(REBALANCE_THREADS), 0, st, w->S, P.A.posIters);
+        {
+            int threads = WAVE;
+            while (threads < REBALANCE_MAX_THREADS && threads * 256 < w->cfg.n_envs) threads *= 2;
+            hipLaunchKernelGGL(rem2d_rebalance_kernel, dim3(1), dim3(threads), 0, st, w->S, P.A.posIters);
+        }
         w->stepsQueued += 1;
     }
     const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&

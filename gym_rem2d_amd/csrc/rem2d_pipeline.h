@@ -420,11 +420,10 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 // world: every thread counts the classes of its contiguous chunk, the counts are scanned in LDS, every thread writes its
 // chunk's creatures to their places; launched every N env-steps in front of `pre`.
 // ---------------------------------------------------------------------------------------------------
-// (One wavefront: it starts as soon as any wavefront slot is free, and the work is a few dozen microseconds either way --
-// 64 / 256 / 1 024 threads measured the same on every workload, profiles/r04_lane_fill_experiments.txt.)
-#ifndef REBALANCE_THREADS
-#define REBALANCE_THREADS 64
-#endif
+// One wavefront for a world of up to ~16 000 creatures (it starts as soon as any wavefront slot is free; 64 / 256 / 1 024 threads
+// measured the same at config 3's world sizes), more for bigger worlds so that a thread's chunk stays at <= 256 creatures
+// (a 262 144-creature world of a 1 M-individual generation: 1 024 threads).
+#define REBALANCE_MAX_THREADS 1024
 #ifndef REBALANCE_CLASSES
 #define REBALANCE_CLASSES 2
 #endif
@@ -439,9 +438,9 @@ DEV int rebalance_class(int positers, int posIters) {
     return positers >= posIters ? 0 : (positers >= 8 ? 1 : (positers >= 3 ? 2 : 3));
 #endif
 }
-__global__ __launch_bounds__(REBALANCE_THREADS) void rem2d_rebalance_kernel(State S, int posIters) {
-    __shared__ int cnt[REBALANCE_CLASSES][REBALANCE_THREADS];
-    const int n = (int)S.nEnvs, T = REBALANCE_THREADS, t = threadIdx.x;
+__global__ __launch_bounds__(REBALANCE_MAX_THREADS) void rem2d_rebalance_kernel(State S, int posIters) {
+    __shared__ int cnt[REBALANCE_CLASSES][REBALANCE_MAX_THREADS];
+    const int n = (int)S.nEnvs, T = (int)blockDim.x, t = threadIdx.x;
     const int per = (n + T - 1) / T;
     const int lo = min(n, t * per), hi = min(n, lo + per);
     int c[REBALANCE_CLASSES];
