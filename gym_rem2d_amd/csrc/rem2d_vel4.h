@@ -254,7 +254,11 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     const int c0 = S.tiles[tile], c1 = S.tiles[tile + 1];
     const int NB = (c1 - c0) * K;               // bodies of this tile (<= V4_MAX_BODIES, checked by the host)
     const unsigned long long rEntry = (V4_DBG(A) & (16 | 64)) ? __builtin_amdgcn_s_memrealtime() : 0; // 100 MHz, chip-wide
-    const bool retile = (S.flags & (REM2D_FLAG_RETILE | REM2D_STATE_ORDERED)) != 0;
+    // A creature order (REM2D_FLAG_RETILE / rem2d_world_set_order / the `rebalance` option) moves creatures between tiles.  The
+    // flexible shapes take any composition (a creature has fewer joints than lanes); a tile of a static shape was planned by the
+    // host for the creatures it holds in ARENA order (<= 64 joints per phase class), so those shapes keep the arena order here
+    // and only the position blocks follow the creature order (the two kernels meet in the arena, per creature).
+    const bool retile = FLEX && (S.flags & (REM2D_FLAG_RETILE | REM2D_STATE_ORDERED)) != 0;
     const int iters = A.velIters;
     const float h = A.dt, mu = friction;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (WAVE - lane));

@@ -211,8 +211,10 @@ int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jround, int32_t
  * dozen steps with a stable sort, so that the static schedule order survives within each class; REM2D_FLAG_RETILE is the
  * same indirection re-dealt by the kernel itself in every step, in arrival order).  order_dev: DEVICE array of
  * rem2d_padded_envs() int32, a permutation of 0 .. padded - 1 (the caller's responsibility), copied asynchronously on
- * `stream`; NULL: back to the identity.  Refused for a world created with REM2D_FLAG_RETILE.  Any order is valid for the
- * default tile plans; a plan made by rem2d_plan_tiles for specific morphologies must be made for the creatures in that order. */
+ * `stream`; NULL: back to the identity.  Refused for a world created with REM2D_FLAG_RETILE.  Any order is valid with any
+ * tile plan: the flexible tile shapes (1, 2, 3) take whatever creatures a tile's slots name, the static ones (0, 4), whose
+ * plan by rem2d_plan_tiles depends on the morphologies a tile holds, keep the arena order in their velocity tiles and follow
+ * the order in their position blocks only. */
 int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream);
 
 /* Launch options of a world.  Like the tile shape they are launch shapes / scheduling hints without a counterpart in the

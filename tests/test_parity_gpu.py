@@ -294,12 +294,13 @@ def test_full_size_chain8(gpu, oracle, flat_terrain):
     env.close()
 
 
-@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies"])
+@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies", "tiles_128_static"])
 @pytest.mark.parametrize("skip_frozen", [False, True])
 def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_frozen, launch):
     """REM2D_FLAG_RETILE: the creatures are dealt to the wavefronts anew in every step (those that used all 60 position
     iterations first; the order comes out of atomics and differs from run to run) -- since round 4 for the velocity tiles as
-    for the position blocks (tile slot e = creature order[e]), in the one-launch form and in the two-launch forms alike.
+    for the position blocks (tile slot e = creature order[e]), in the one-launch form and in the two-launch forms alike (a
+    static tile shape keeps the arena order in its velocity tiles: the host planned them for it).
     Creatures are independent:
     poses, velocities, sleep state, reward, fitness and step counts equal the oracle's in every bit, also together with
     REM2D_FLAG_SKIP_FROZEN (wavefronts of pre whose creatures have all finished are skipped; post must leave exactly those
@@ -312,7 +313,7 @@ def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_f
     T = 420 if skip_frozen else 240     # (long enough for whole wavefronts of 8 creatures to have finished)
     w = gpu(morph.n_envs, morph.lanes, flags, options={"fuse_velpost": 0} if launch == "two_launches" else None)
     w.set_terrain(rough_terrain)
-    w.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    w.reset(morph, tile_shape={"tiles_128_bodies": 1, "tiles_128_static": 4}.get(launch))
     snaps = []
     for c in [1, 59, T - 60]:
         w.step(c)
@@ -334,12 +335,14 @@ def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_f
     w.close()
 
 
-@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies", "fused_step_kernel"])
+@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies", "tiles_128_static", "tiles_256_static",
+                                    "fused_step_kernel"])
 def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch):
     """rem2d_world_set_order: slot e of the velocity tiles / position blocks handles creature order[e].  Any permutation --
     here a random one, changed twice in mid-run, then back to the identity -- leaves poses, velocities, sleep state,
     reward and fitness equal to the oracle's in every bit (creatures are independent), in the one-launch form, the two
-    launches, the 128-body tiles and (where the order has no meaning and is ignored) the fused step kernel."""
+    launches, the 128-body tiles, the static tile shapes (whose velocity tiles were planned for the arena order and keep it:
+    only their position blocks follow the order) and (where the order has no meaning and is ignored) the fused step kernel."""
     import torch
     from gym_rem2d_amd import _lib, synthetic
     from gym_rem2d_amd.compiler import Morphology
@@ -348,7 +351,8 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     opts = {"two_launches": {"fuse_velpost": 0}, "fused_step_kernel": {"pipeline": 0}}.get(launch)
     w = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
     w.set_terrain(rough_terrain)
-    w.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    shape = {"tiles_128_bodies": 1, "tiles_128_static": 4, "tiles_256_static": 0}.get(launch)
+    w.reset(morph, tile_shape=shape)
     g = torch.Generator().manual_seed(7)
     T = 0
     for chunk, order in ((40, torch.randperm(morph.n_envs, generator=g)), (80, torch.randperm(morph.n_envs, generator=g)),
@@ -377,7 +381,7 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     opts = dict(opts or {}, rebalance=7)
     d = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
     d.set_terrain(rough_terrain)
-    d.reset(morph, tile_shape=1 if launch == "tiles_128_bodies" else None)
+    d.reset(morph, tile_shape=shape)
     for chunk in (40, 80, 60, 40):
         d.step(chunk)
     assert np.array_equal(d.bodies(), ref["bodies"]) and np.array_equal(d.view("fitness").cpu().numpy(), ref["fitness"])
