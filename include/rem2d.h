@@ -269,7 +269,8 @@ int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n
  * whose `stream` is NULL runs on `stream` itself.  Same result as rem2d_worlds_step on every group.
  * flags: REM2D_STEP_GRAPH -- capture the call's launches and fork / join edges into a hipGraph the first time and replay it
  * with one hipGraphLaunch afterwards (re-captured when a world's tiles / outputs / terrain change; ignored while kernel
- * timing is on). */
+ * timing is on).  A replay repeats the launches of the captured call, those of REM2D_OPT_REBALANCE included: the cadence of the
+ * re-ordering is then that of the captured call, not N env-steps (a launch shape either way; no result depends on it). */
 #define REM2D_MAX_STEP_GROUPS 16
 #define REM2D_STEP_GRAPH 1u
 typedef struct {

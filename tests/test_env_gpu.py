@@ -127,10 +127,11 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
     for k in sorted(groups):
         m = Morphology.from_specs([specs[e] for e in groups[k]], k)
         ref[groups[k]] = oracle.batch_run(ot, m.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)["fitness"]
-    for n_groups, graph in ((1, False), (3, False), (4, False), (4, True), (3, True)):
+    for n_groups, graph, rebalance in ((1, False, 0), (3, False, 0), (4, False, 0), (4, True, 0), (3, True, 0), (4, True, 7)):
         env = BatchedModular2D(seed=4, flags=_lib.FLAG_CONTINUOUS)
         env.step_groups = n_groups
         env.use_graph = graph
+        env.rebalance_every = rebalance   # (under a graph the re-ordering launches of the captured call are replayed with it)
         env.reset_specs(specs)
         assert len(env.groups) == n_groups
         if not any(k in os.environ for k in ("REM2D_TILE_SHAPE", "REM2D_FUSE_VELPOST", "REM2D_PIPELINE", "REM2D_RETILE")):
@@ -139,7 +140,7 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
         for n in (1, 24, 25, 25, 25, 25, 25):      # (25 five times: the graph of that length is captured once, replayed four times)
             env.step(n)
         torch.cuda.synchronize()
-        assert np.array_equal(env.fitness.cpu().numpy(), ref), (n_groups, graph)
+        assert np.array_equal(env.fitness.cpu().numpy(), ref), (n_groups, graph, rebalance)
         assert bool((env.steps == T).all()) and int(env.errors().max()) == 0
         env.close()
     L = _lib.lib()

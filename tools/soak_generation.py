@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--max-modules", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=8192, help="individuals per oracle call (bounds host memory)")
+    ap.add_argument("--encoding", choices=["lsystem", "network"], default="lsystem",
+                    help="network: config 4's generator (one network-encoded creature per seed) on the hardcore track")
     args = ap.parse_args()
     from gym_rem2d_amd import _lib, make_terrain
     from gym_rem2d_amd.env import BatchedModular2D
@@ -33,10 +35,18 @@ def main():
     from oracle import oracle as O
     O.build()
     rng = np.random.default_rng(args.seed)
-    pop = LSystemPopulation.random(args.n, rng, max_modules=args.max_modules)
-    terrain = make_terrain(4)
-    env = BatchedModular2D(flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
-    env._upload(pop.compile(0), args.n)
+    hard = args.encoding == "network"
+    terrain = make_terrain(4, hardcore=hard)
+    if hard:
+        from gym_rem2d_amd import synthetic
+        batches = [(m, np.asarray(idx, dtype=np.int64)) for m, idx in
+                   synthetic.cppn_batches_native(range(args.seed * 10 ** 6, args.seed * 10 ** 6 + args.n), n_proc=4)]
+        select = None
+    else:
+        pop = LSystemPopulation.random(args.n, rng, max_modules=args.max_modules)
+        batches = pop.compile(0)
+    env = BatchedModular2D(hardcore=hard, flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
+    env._upload(batches, args.n)
     shapes = sorted({int(w.tile_shape) for w, _ in env.worlds})
     t0 = time.time()
     fit = run_episode(env, max_steps=args.cap).cpu().numpy()
@@ -46,17 +56,27 @@ def main():
     sample = np.arange(args.n) if args.check >= 1.0 else \
         np.union1d(rng.choice(args.n, int(args.n * args.check), replace=False), np.asarray(overflow, dtype=np.int64))
     xs, ys, polys = terrain.f32()
-    ot = O.Terrain(xs, ys, None, terrain.friction)
+    ot = O.Terrain(xs, ys, polys if len(polys) else None, terrain.friction)
     ref = np.full(args.n, np.nan)
     t0 = time.time()
-    for lo in range(0, len(sample), args.chunk):
-        part = sample[lo:lo + args.chunk]
-        for m, idx in pop.select(part).compile(0):
-            r = O.batch_run(ot, m.as_dict(), args.cap, n_threads=os.cpu_count() or 1, flags=O.FLAG_CONTINUOUS)
-            ref[part[np.asarray(idx)]] = r["fitness"]
+    if hard:   # the lane buckets as uploaded, in chunks of their creatures (Morphology.take keeps the layout)
+        want = np.zeros(args.n, dtype=bool)
+        want[sample] = True
+        for m, idx in batches:
+            keep = np.nonzero(want[idx])[0]
+            for lo in range(0, len(keep), args.chunk):
+                part = keep[lo:lo + args.chunk]
+                r = O.batch_run(ot, m.take(part).as_dict(), args.cap, n_threads=os.cpu_count() or 1, flags=O.FLAG_CONTINUOUS)
+                ref[idx[part]] = r["fitness"]
+    else:
+        for lo in range(0, len(sample), args.chunk):
+            part = sample[lo:lo + args.chunk]
+            for m, idx in pop.select(part).compile(0):
+                r = O.batch_run(ot, m.as_dict(), args.cap, n_threads=os.cpu_count() or 1, flags=O.FLAG_CONTINUOUS)
+                ref[part[np.asarray(idx)]] = r["fitness"]
     t_cpu = time.time() - t0
     bad = int((fit[sample] != ref[sample]).sum())
-    print(json.dumps(dict(individuals=args.n, cap=args.cap, checked=int(len(sample)), mismatching=bad, wide_fallback=len(overflow),
+    print(json.dumps(dict(encoding=args.encoding, individuals=args.n, cap=args.cap, checked=int(len(sample)), mismatching=bad, wide_fallback=len(overflow),
                           tile_shapes=shapes, gpu_seconds=round(t_gpu, 1), oracle_seconds=round(t_cpu, 1),
                           fitness_mean=float(fit.mean()), fitness_max=float(fit.max()))), flush=True)
     print("SOAK " + ("OK" if bad == 0 else "MISMATCH"))

@@ -24,7 +24,11 @@ def main():
     ap.add_argument("--rebalance", type=int, default=37,
                     help="launch option `rebalance`: the library re-makes every world's creature order on the device every N env-steps "
                          "(0 = off); the default is an odd cadence so that the orders change at many different step numbers")
+    ap.add_argument("--flags", type=int, default=1, help="world flags, bits 1 | 2 | 4 (continuous, sleep-reset-always, no-sleep): the same "
+                                                         "bits mean the same on both sides")
+    ap.add_argument("--wide", action="store_true", help="the wide-slot build librem2d_wide.so (the overflow fallback's library)")
     args = ap.parse_args()
+    assert args.flags & ~7 == 0
     import bench
     from gym_rem2d_amd import make_terrain
     from gym_rem2d_amd.compiler import Morphology
@@ -64,7 +68,8 @@ def main():
         t0 = time.time()
         stats = dict(toi_events=0, max_pairs=0, max_positers=0, creatures=0, bodies=0)
         for m, idx in batches:
-            w = BatchedWorld(m.n_envs, m.lanes, 1, options={"rebalance": args.rebalance} if args.rebalance > 0 else None)
+            w = BatchedWorld(m.n_envs, m.lanes, args.flags, wide=args.wide,
+                             options={"rebalance": args.rebalance} if args.rebalance > 0 else None)
             w.set_terrain(terrain)
             w.reset(m)
             w.step(args.steps)
@@ -75,13 +80,13 @@ def main():
             stats["max_positers"] = max(stats["max_positers"], int(w.view("positers").max()))
             assert int(w.view("err").max()) == 0, "solver / pair overflow flagged"
             w.close()
-            ref = O.batch_run(ot, m.as_dict(), args.steps, n_threads=os.cpu_count() or 1, flags=1)
+            ref = O.batch_run(ot, m.as_dict(), args.steps, n_threads=os.cpu_count() or 1, flags=args.flags)
             same = np.array_equal(got, ref["bodies"]) and np.array_equal(fit, ref["fitness"])
             if not same:
                 bad += int((~(got == ref["bodies"]).all(axis=(1, 2))).sum())
             stats["creatures"] += m.n_envs
             stats["bodies"] += int(m.n_bodies.sum())
-        report.append(dict(case=name, steps=args.steps, rebalance_every=args.rebalance, mismatching_creatures=bad,
+        report.append(dict(case=name, steps=args.steps, flags=args.flags, wide=args.wide, rebalance_every=args.rebalance, mismatching_creatures=bad,
                            seconds=round(time.time() - t0, 1), **stats))
         print(json.dumps(report[-1]), flush=True)
     ok = all(r["mismatching_creatures"] == 0 for r in report)
