@@ -437,22 +437,26 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
     morph = _populations()["lsystem_k16"]
     ot = oracle_terrain(oracle, rough_terrain)
     steps = 120
-    w = gpu(morph.n_envs, morph.lanes, flags)
-    w.set_terrain(rough_terrain)
-    w.reset(morph)
-    w.step_ex(steps, 1.0 / 50, vel_iters, pos_iters)
-    got = w.bodies()
-    used = w.view("positers").cpu().numpy()
-    assert int(w.view("err").max()) == 0
-    w.close()
     d = morph.as_dict()
+    refs = []
     for e in range(morph.n_envs):
         ow = oracle.World.from_morph(ot, d, e, flags)
         for _ in range(steps):
             ow.env_step_ex(1.0 / 50, vel_iters, pos_iters)
-        ref = ow.bodies()
-        assert np.array_equal(got[e, : ref.shape[0]], ref), e
-        assert used[e] == ow.position_iterations
+        refs.append((ow.bodies(), ow.position_iterations))
+    # the default 64-body tiles, the 128-body flexible and static shapes, velocity tiles + position blocks in two launches
+    for shape, opts in ((None, None), (1, None), (4, None), (None, {"fuse_velpost": 0}), (None, {"rebalance": 9})):
+        w = gpu(morph.n_envs, morph.lanes, flags, options=opts)
+        w.set_terrain(rough_terrain)
+        w.reset(morph, tile_shape=shape)
+        w.step_ex(steps, 1.0 / 50, vel_iters, pos_iters)
+        got = w.bodies()
+        used = w.view("positers").cpu().numpy()
+        assert int(w.view("err").max()) == 0
+        w.close()
+        for e, (ref, iters) in enumerate(refs):
+            assert np.array_equal(got[e, : ref.shape[0]], ref), (e, shape, opts)
+            assert used[e] == iters
     print('position iterations used: max %d of %d' % (used.max(), pos_iters))
     assert used.max() == pos_iters or pos_iters > 60   # with the usual budgets some creature runs out of iterations
 
