@@ -389,6 +389,19 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     d.close()
 
 
+def test_launch_shapes_may_change_between_step_calls(gpu, oracle):
+    """The state arena does not care how it is stepped: formulation, one or two launches, tile shape and tile plan, creature
+    order (host- / device-made), issue priority and TOI bodies per wavefront are changed at random between step calls of
+    random lengths (tools/fuzz_launch_shapes.py, a few rounds of it; 340 rounds: profiles/r04_fuzz_launch_shapes.txt) and the
+    final state still equals the oracle's run of the same number of steps in every bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_launch_shapes
+    lines = []
+    assert fuzz_launch_shapes.fuzz(8, 5, 500, report=lines.append) == 0, lines
+
+
 def test_determinism(gpu, rough_terrain):
     morph = _populations()["lsystem_k16"]
     _, a = _run_gpu(gpu, morph, rough_terrain, [150])
