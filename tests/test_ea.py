@@ -107,7 +107,7 @@ def test_parallel_encoder_equals_serial_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("encoding", ["lsystem", "direct"])
+@pytest.mark.parametrize("encoding", ["lsystem", "direct", "cppn"])
 def test_generation_on_gpu_equals_generation_with_the_oracle(encoding, oracle):
     """(f2) The EA generation of REM2D_main.py:280-298 -- tournament-4, clone, mutate, evaluate -- run twice from the
     same seed: once with the batched GPU episode as the evaluator, once with the CPU oracle.  Fitness feeds selection,

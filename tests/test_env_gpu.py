@@ -151,6 +151,18 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
     assert L.rem2d_worlds_launch_info(None, 0, None, None) == -1
 
 
+def test_episode_with_random_step_lengths_and_compactions(need_gpu, oracle):
+    """An evaluate() episode driven at random (tools/fuzz_episode.py, a few rounds of it; 180 rounds:
+    profiles/r04_fuzz_episode.txt): step calls of random lengths, compact() with random thresholds -- also while most creatures are
+    alive and in mid-flight --, 1-4 step groups, device-made creature orders at random cadences, hipGraph replay or not.  The
+    float64 fitness of every individual equals the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_episode
+    lines = []
+    assert fuzz_episode.fuzz(5, 7, max_creatures=900, cap=400, report=lines.append) == 0, lines
+
+
 def test_array_population_fitness_is_order_independent(need_gpu):
     """population.LSystemPopulation -> native compiler -> batched episodes: the fitness of an individual does not
     depend on where it sits in the population (bucket sorting / step groups / index gathering are transparent)."""
