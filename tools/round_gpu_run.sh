@@ -27,3 +27,5 @@ import json,sys; d=json.load(open('$f')); c=d['config']; print('$f'.split('/')[-
 cat $O/facade.txt
 bash tools/profile_round.sh ${TAG%_final} > $O/profile.log 2>&1; tail -3 $O/profile.log
 timeout 600 python tools/soak_parity.py --n 6000 --steps 300 > $O/soak_parity.txt 2>&1; tail -4 $O/soak_parity.txt
+timeout 600 python tools/fuzz_launch_shapes.py --rounds 40 --seed 1 > $O/fuzz_launch_shapes.txt 2>&1; tail -1 $O/fuzz_launch_shapes.txt
+timeout 600 python tools/fuzz_episode.py --rounds 30 --seed 1 > $O/fuzz_episode.txt 2>&1; tail -1 $O/fuzz_episode.txt
