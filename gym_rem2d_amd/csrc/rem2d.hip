@@ -771,6 +771,9 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 #ifndef REM2D_SHAPE1_WPS
 #define REM2D_SHAPE1_WPS 4 // wavefronts per SIMD the 128-body tile shape is compiled for
 #endif
+#ifndef REM2D_SHAPE4_WPS
+#define REM2D_SHAPE4_WPS 3 // the same for the static 128-body shape of the fixed-morphology populations (4: 128 VGPRs, 3 spilled; 65 536 8-module chains 164 instead of 185 M)
+#endif
 #ifndef REM2D_SHAPE1_PAIR
 #define REM2D_SHAPE1_PAIR false // (lane-pair contact solves: a 128-body tile's manifolds rarely fit 32 lanes; without them 3 VGPR spills instead of 7, +2.7 % at 393 216 creatures)
 #endif
@@ -809,7 +812,7 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
             case 0: hipExtLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             case 1: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             case 2: hipExtLaunchKernelGGL((rem2d_vel4_kernel<3, 3, 1, 3, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
-            case 4: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
+            case 4: hipExtLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE4_WPS, false, false>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             default: hipExtLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, e0, e1, 0, P.VB, P.V); break;
             }
             w0->evUsed += 1;
@@ -818,7 +821,7 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
             case 0: hipLaunchKernelGGL((rem2d_vel4_kernel<4, 4, 2, 2, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             case 1: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE1_WPS, REM2D_SHAPE1_PAIR>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             case 2: hipLaunchKernelGGL((rem2d_vel4_kernel<3, 3, 1, 3, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
-            case 4: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, 3, false, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
+            case 4: hipLaunchKernelGGL((rem2d_vel4_kernel<2, 2, 1, REM2D_SHAPE4_WPS, false, false>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             default: hipLaunchKernelGGL((rem2d_vel4_kernel<1, 1, 1, 4, true>), dim3(P.tiles), block, 0, st, P.VB, P.V); break;
             }
         }
