@@ -115,21 +115,56 @@ class Rem2dError(RuntimeError):
     pass
 
 
+# -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov) than it saves here;
+# without it the step kernel fits 238 VGPRs with no spills (+11..14 % env-steps/s).  -ffp-contract=off keeps every binary32
+# operation separately rounded (what the bit-exact parity rests on).
+BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared"]
+WIDE_FLAGS = ["-DREM2D_WIDE=1"]
+INCLUDE_DIR = os.path.join(_ROOT, "include")
+_ID_MARKER = b"REM2D_BUILD_ID="
+
+
+def source_id(extra=()):
+    """Identity of a build of the library as the sources stand NOW: sha256 over every file under csrc/ (name and bytes, in
+    name order), include/rem2d.h and the compile flags, 16 hex digits.  build() compiles it in (-DREM2D_BUILD_ID), lib()
+    compares it with rem2d_build_id() and refuses a library built from anything else."""
+    import hashlib
+    csrc = os.path.dirname(SRC_PATH)
+    h = hashlib.sha256()
+    for path in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(INCLUDE_DIR, "rem2d.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(BUILD_FLAGS + list(extra)).encode())
+    return h.hexdigest()[:16]
+
+
+def file_build_id(path):
+    """The build id compiled into a library file, read from its bytes (no dlopen: that would pin /opt/rocm's HIP runtime
+    before torch has loaded its own); None for a missing file or one without the marker."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_ID_MARKER)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(_ID_MARKER):j].decode("ascii", "replace")
+
+
 def build(force=False, verbose=False):
     """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so and (-DREM2D_WIDE) librem2d_wide.so (hipcc
-    cross-compiles without a GPU; the two compile side by side).  -ffp-contract=off keeps every binary32 operation
-    separately rounded."""
-    csrc = os.path.dirname(SRC_PATH)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "rem2d.h")]
-    newest = max(os.path.getmtime(d) for d in deps)
+    cross-compiles without a GPU; the two compile side by side).  A library is rebuilt when the id compiled into it differs
+    from source_id() -- the hash of the sources and flags, not a file time."""
     procs = []
-    for path, extra in ((LIB_PATH, []), (WIDE_LIB_PATH, ["-DREM2D_WIDE=1"])):
-        if not force and os.path.exists(path) and os.path.getmtime(path) >= newest:
+    for path, extra in ((LIB_PATH, []), (WIDE_LIB_PATH, WIDE_FLAGS)):
+        want = source_id(extra)
+        if not force and file_build_id(path) == want:
             continue
-        # -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov)
-        # than it saves here; without it the step kernel fits 238 VGPRs with no spills (+11..14 % env-steps/s)
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
-               "-shared"] + extra + ["-I" + os.path.join(_ROOT, "include"), SRC_PATH, "-o", path]
+        cmd = ["hipcc"] + BUILD_FLAGS + extra + ['-DREM2D_BUILD_ID="%s"' % want, "-I" + INCLUDE_DIR, SRC_PATH, "-o", path]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -144,6 +179,11 @@ def build(force=False, verbose=False):
 
 _lib = None
 _libs = {}
+
+
+def build_id(wide=False):
+    """rem2d_build_id() of the loaded library (bench.py prints it)."""
+    return lib(wide).rem2d_build_id().decode()
 
 
 def capacity(wide=False):
@@ -213,8 +253,16 @@ def lib(wide=False):
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 8:
+    if L.rem2d_abi_version() != 9:
         raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
+    L.rem2d_build_id.restype = C.c_char_p
+    # the library must have been built from the sources beside it (REM2D_LIB_PATH / REM2D_WIDE_LIB_PATH name an experiment's
+    # variant build on purpose: tools/build_variant.sh, exempt)
+    overridden = os.environ.get("REM2D_WIDE_LIB_PATH" if wide else "REM2D_LIB_PATH")
+    have, want = L.rem2d_build_id().decode(), source_id(WIDE_FLAGS if wide else [])
+    if not overridden and have != want:
+        raise Rem2dError("%s is stale: built from sources with id %s, the sources here have id %s -- rebuild it with "
+                         "`python -c 'import __graft_entry__ as g; g.build()'`" % (os.path.basename(path), have, want))
     if wide:
         _libs[True] = L
     else:

@@ -131,7 +131,13 @@ struct rem2d_world {
     uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
     int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
     int64_t stepsQueued;          // env-steps queued so far (the cadence of REM2D_OPT_REBALANCE)
+    bool hostOrder;               // rem2d_world_set_order installed an order (REM2D_STATE_ORDERED = hostOrder || REBALANCE > 0)
 };
+// the kernels go through State::order while the host has installed an order OR the library re-makes one every N steps
+static void order_flag_update(rem2d_world *w) {
+    if (w->hostOrder || w->opt[REM2D_OPT_REBALANCE] > 0) w->S.flags |= REM2D_STATE_ORDERED;
+    else w->S.flags &= ~REM2D_STATE_ORDERED;
+}
 
 // Tile shape of rem2d_vel4_kernel (rem2d_world_set_tile_shape; rem2d_vel4.h explains the trade-off):
 //   0: 256 bodies, 4 joint sets, 2 contact sets, 2 waves/SIMD   1: 128 bodies, 2 + 1 sets, 4 waves/SIMD (round 4)
@@ -187,6 +193,15 @@ static uint32_t __float_as_uint_host(float f) {
 }
 
 extern "C" int rem2d_abi_version(void) { return REM2D_ABI_VERSION; }
+// Build identity: the builder (gym_rem2d_amd/_lib.py build(), tools/build_variant.sh) hashes every file under csrc/, include/rem2d.h
+// and the compile flags into -DREM2D_BUILD_ID; the loader recomputes the hash from the sources beside it and refuses a library
+// built from anything else (the .so files are git-ignored yet travel to the GPU box: a stale one must not be benched silently).
+// The marker in front lets a tool read the id from the file without dlopen.
+#ifndef REM2D_BUILD_ID
+#define REM2D_BUILD_ID "unidentified"
+#endif
+static const char kBuildId[] = "REM2D_BUILD_ID=" REM2D_BUILD_ID;
+extern "C" const char *rem2d_build_id(void) { return kBuildId + 15; }
 extern "C" const char *rem2d_last_error(void) { return g_err.c_str(); }
 extern "C" int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots) {
     if (contact_slots) *contact_slots = REM2D_CONTACT_SLOTS;
@@ -258,6 +273,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->epoch = next_epoch();
     for (int k = 0; k < REM2D_OPT_COUNT; ++k) w->opt[k] = kOptDefault[k];
     w->stepsQueued = 0;
+    w->hostOrder = false;
     bind_state(w);
     w->S.scr = nullptr;
     hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
@@ -348,10 +364,20 @@ extern "C" int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, v
         // both halves (the REM2D_FLAG_RETILE machinery reads the first, swaps in the second): what the kernels read stays put
         HIP_TRY(hipMemcpyAsync(w->S.order, order_dev, (size_t)w->L.Np * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         HIP_TRY(hipMemcpyAsync(w->S.order + w->L.Np, order_dev, (size_t)w->L.Np * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        w->S.flags |= REM2D_STATE_ORDERED;
+        w->hostOrder = true;
     } else {
-        w->S.flags &= ~REM2D_STATE_ORDERED;
+        // back to the arena order.  With REM2D_OPT_REBALANCE on the kernels keep going through State::order (the library
+        // re-makes it every N steps), so the identity is written there instead of dropping the indirection
+        if (w->hostOrder && w->opt[REM2D_OPT_REBALANCE] > 0) {
+            std::vector<int> ident((size_t)w->L.Np);
+            for (int i = 0; i < w->L.Np; ++i) ident[(size_t)i] = i;
+            HIP_TRY(hipDeviceSynchronize()); // (rare call: no kernel of any step group may still read the old order)
+            HIP_TRY(hipMemcpy(w->S.order, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(w->S.order + w->L.Np, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        w->hostOrder = false;
     }
+    order_flag_update(w);
     w->epoch = next_epoch();
     return REM2D_OK;
 }
@@ -364,14 +390,14 @@ extern "C" int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value
     if (key == REM2D_OPT_REBALANCE) {
         if (value > 0 && (w->cfg.flags & REM2D_FLAG_RETILE))
             return fail(REM2D_E_INVALID, "set_option: the world deals its creatures itself (REM2D_FLAG_RETILE)");
-        // the kernels go through State::order from now on (the identity until the first rebalance) / directly again
-        if (value > 0) w->S.flags |= REM2D_STATE_ORDERED;
-        else if (w->opt[key] > 0) w->S.flags &= ~REM2D_STATE_ORDERED;
     }
     if (w->opt[key] != value) {
         w->opt[key] = value;
         w->epoch = next_epoch(); // (a captured replay of the old launch sequence is stale)
     }
+    // REBALANCE: the kernels go through State::order from now on (the identity, or the host's order, until the first
+    // rebalance) / directly again unless the host has an order installed (rem2d_world_set_order)
+    if (key == REM2D_OPT_REBALANCE) order_flag_update(w);
     return REM2D_OK;
 }
 extern "C" int rem2d_world_get_option(const rem2d_world *w, int32_t key, int32_t *value) {
@@ -688,6 +714,19 @@ extern "C" int rem2d_world_reset(rem2d_world *w, const rem2d_morph *m, void *str
 }
 
 static int pipeline_mode(const rem2d_world *w) { return w->opt[REM2D_OPT_PIPELINE] == 0 ? 0 : 3; }
+// Worlds of one merged launch run in ONE kernel shape (tiles_plan: the highest tile_shape_rank).  Every mix is sound but one: a
+// tile planned for shape 2 (192 bodies, <= 192 joints IN ALL, flexibly placed) may hold more than 64 joints in one schedule
+// phase, which the static four-set kernel of shape 0 (one phase per register set) cannot take -- that launch would drop joints.
+static bool shapes_mix_ok(rem2d_world *const *ws, int n_worlds) {
+    bool has0 = false, has2 = false;
+    for (int i = 0; i < n_worlds; ++i) {
+        has0 = has0 || ws[i]->tileShape == 0;
+        has2 = has2 || ws[i]->tileShape == 2;
+    }
+    return !(has0 && has2);
+}
+#define SHAPES_TRY(ws, n) \
+    do { if (!shapes_mix_ok((ws), (n))) return fail(REM2D_E_INVALID, "worlds of tile shapes 0 and 2 cannot share a launch (step them in separate calls / groups)"); } while (0)
 
 // The tile pipeline for one or several worlds (lane buckets) in one grid per kernel: pre and post run one body per
 // lane; the velocity iterations run one tile per wavefront (rem2d_vel4.h).  TilePlan = the launch arguments of one env-step of
@@ -780,6 +819,9 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
 static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     rem2d_world *w0 = P.w0;
     const dim3 grid(P.blocks), block(WAVE);
+    // (the step's time bracket opens in front of the re-ordering launches: they belong to the step that needs them)
+    const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
+                           hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
     for (int i = 0; i < P.nw; ++i) { // REM2D_OPT_REBALANCE: a new creature order every N env-steps, made from the last step's state
         rem2d_world *w = P.ws[i];
         const int every = w->opt[REM2D_OPT_REBALANCE];
@@ -791,8 +833,6 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
         }
         w->stepsQueued += 1;
     }
-    const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
-                           hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
     // (a merged launch of shapes 1 and 4: rank picks 1, whose flexible kernel takes the statically planned tiles too)
     if (P.launchShape == 3 || (P.launchShape == 1 && REM2D_SHAPE1_WPS >= 4)) hipLaunchKernelGGL(rem2d_pre_multi_kernel<4>, grid, block, 0, st, P.B, P.A);
     else hipLaunchKernelGGL(rem2d_pre_multi_kernel<3>, grid, block, 0, st, P.B, P.A);
@@ -893,6 +933,7 @@ extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds
     static TilePlan P; // (large: kernel arguments of a whole group)
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
+    SHAPES_TRY(ws, n_worlds);
     tiles_plan(P, ws, n_worlds, 1.0f / 50.0f, 180, 60);
     if (tile_shape_out) *tile_shape_out = P.launchShape;
     if (fused_velpost) *fused_velpost = P.velpost ? 1 : 0;
@@ -939,7 +980,10 @@ extern "C" int rem2d_worlds_step_ex(rem2d_world *const *ws, int32_t n_worlds, in
     if (n_steps <= 0) return REM2D_OK;
     rem2d_world *w0 = ws[0];
     HIP_TRY(hipSetDevice(w0->cfg.device));
-    if (pipeline_mode(w0) == 3) return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    if (pipeline_mode(w0) == 3) {
+        SHAPES_TRY(ws, n_worlds);
+        return step_tiles(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
+    }
     return step_fused(ws, n_worlds, n_steps, dt, vel_iters, pos_iters, (hipStream_t)stream);
 }
 extern "C" int rem2d_worlds_step(rem2d_world *const *ws, int32_t n_worlds, int32_t n_steps, void *stream) {
@@ -1061,6 +1105,8 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
         if (!wg->evJoin) HIP_TRY(hipEventCreateWithFlags(&wg->evJoin, hipEventDisableTiming));
     }
     const bool tiles = pipeline_mode(w00) == 3;
+    if (tiles)
+        for (int g = 0; g < n_groups; ++g) SHAPES_TRY(groups[g].worlds, groups[g].n_worlds);
     hipStream_t origin = (hipStream_t)stream;
     if (!(flags & REM2D_STEP_GRAPH) || timing || !tiles)
         return groups_enqueue(groups, n_groups, n_steps, dt, vel_iters, pos_iters, origin, tiles);
@@ -1073,8 +1119,13 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
     for (int g = 0; g < n_groups; ++g) {
         key = mix64(key, (uint64_t)(uintptr_t)groups[g].stream);
         for (int i = 0; i < groups[g].n_worlds; ++i) {
-            key = mix64(key, (uint64_t)(uintptr_t)groups[g].worlds[i]);
-            key = mix64(key, groups[g].worlds[i]->epoch);
+            const rem2d_world *w = groups[g].worlds[i];
+            key = mix64(key, (uint64_t)(uintptr_t)w);
+            key = mix64(key, w->epoch);
+            // REM2D_OPT_REBALANCE: which steps of the call carry a re-ordering launch depends on where the call starts in the
+            // cadence -- part of the key, so that a replay re-orders every N env-steps exactly like the plain enqueue does
+            const int every = w->opt[REM2D_OPT_REBALANCE];
+            if (every > 0) key = mix64(key, 0xabcd0000ull + (uint64_t)(w->stepsQueued % every));
         }
         key = mix64(key, 0xfeedull + (uint64_t)groups[g].n_worlds);
     }
@@ -1111,6 +1162,9 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
             for (int i = 0; i < groups[g].n_worlds; ++i) ge.worlds.push_back(groups[g].worlds[i]);
         g_graphs.push_back(ge);
         hit = &g_graphs.back();
+    } else { // (a capture advances the worlds' step counters itself, tiles_launch_step; a replay does it here)
+        for (int g = 0; g < n_groups; ++g)
+            for (int i = 0; i < groups[g].n_worlds; ++i) groups[g].worlds[i]->stepsQueued += n_steps;
     }
     HIP_TRY(hipGraphLaunch(hit->exec, origin));
     return REM2D_OK;

@@ -680,9 +680,11 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
         }
     }
     err = wave_or(err);
-    if (err && lane == 0) {
-        const unsigned env = retile ? (unsigned)S.order[c0] : (unsigned)c0;
-        atomicOr(&EI(E_ERR), err);
+    if (err) { // a tile that breaks the host's rule leaves joints of ANY of its creatures unsolved: all of them carry the flag
+        for (int e = c0 + lane; e < c1; e += WAVE) {
+            const unsigned env = retile ? (unsigned)S.order[e] : (unsigned)e;
+            atomicOr(&EI(E_ERR), err);
+        }
     }
     if ((V4_DBG(A) & 64) && lane == 0) { // diagnostic (tools/chain_probe.py): this wavefront's time in the kernel, 100 MHz ticks
         const unsigned env = (unsigned)c0;

@@ -267,13 +267,14 @@ def all_gather_fitness(local, n_total, group=None, flags=None):
     return fit, out[:, 1].reshape(-1)[:n_total] != 0
 
 
-def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on_error="penalty"):
+def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on_error="raise"):
     """Shard [0, n_total) over the job's ranks, evaluate the local block with
     ``local_eval(lo, hi) -> tensor[hi-lo]`` (or ``-> (tensor, unresolved mask)``, run_episode_masked) and all-gather.
     Returns fitness[n_total] (float64).  The mask rides in the same collective, so every rank learns about every rank's
-    unresolved creatures AFTER it: with on_error="penalty" (default) they get UNRESOLVED_FITNESS on every rank alike
-    (``evaluate_population_sharded.last_unresolved`` lists them) and the job goes on; with "raise" every rank raises
-    SolverOverflow in step."""
+    unresolved creatures AFTER it: with on_error="raise" (the library default -- the reference has no contact cap and would
+    have produced a fitness) every rank raises SolverOverflow in step; with "penalty" (an EA loop's opt-in) they get
+    UNRESOLVED_FITNESS on every rank alike, every rank warns, ``evaluate_population_sharded.last_unresolved`` lists them and
+    the job goes on."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_total, rank, world)
@@ -290,5 +291,5 @@ def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on
         if on_error != "penalty":
             idx = torch.nonzero(bad).flatten().cpu().tolist()
             raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
-        evaluate_population_sharded.last_unresolved = apply_penalty(fit, bad, warn=rank == 0)
+        evaluate_population_sharded.last_unresolved = apply_penalty(fit, bad, warn=True)
     return fit

@@ -201,12 +201,18 @@ def run_generations(pop, n_generations, evaluate, rng, morph_rate=0.01, rate=0.0
     return pop, fit, history
 
 
-def sharded_evaluator(local_eval, group=None, device=None, on_error="penalty"):
+def sharded_evaluator(local_eval, group=None, device=None, on_error="raise"):
     """evaluate(population) for a torch.distributed job (one process per GPU): every rank holds the whole
     population as arrays (selection and mutation are replicated from a shared seed, so no genome ever crosses a
     rank boundary), expresses and evaluates only its contiguous block ``[lo, hi)`` with
     ``local_eval(LSystemPopulation block) -> fitness[hi-lo]`` and the ranks exchange one all-gather of float64
-    fitness (REM2D_main.py:256-267 pool.map)."""
+    fitness (REM2D_main.py:256-267 pool.map).
+
+    on_error: what to do about creatures without a valid fitness (beyond even the wide build's contact slots -- Box2D has
+    no such cap, so the reference would have produced a number).  "raise" (the library default): every rank raises
+    SolverOverflow AFTER the collective, in step.  "penalty" (what an EA loop opts into so that one out-of-domain creature
+    does not abort a run): evaluate.UNRESOLVED_FITNESS on every rank alike, a warning on EVERY rank, and the indices kept per
+    call in ``evaluate.unresolved_log`` (a list that grows by one entry per call: a long run cannot lose them)."""
     import torch
     import torch.distributed as dist
     from .evaluate import all_gather_fitness, shard_range
@@ -232,17 +238,22 @@ def sharded_evaluator(local_eval, group=None, device=None, on_error="penalty"):
             if on_error != "penalty":
                 idx = torch.nonzero(bad).flatten().cpu().tolist()
                 raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
-            evaluate.last_unresolved = apply_penalty(fit, bad, warn=rank == 0)
+            evaluate.last_unresolved = apply_penalty(fit, bad, warn=True)
+        evaluate.unresolved_log.append(list(evaluate.last_unresolved))
         return fit.cpu().numpy().astype(np.float64)
+    evaluate.last_unresolved = []
+    evaluate.unresolved_log = []
     return evaluate
 
 
-def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False, on_error="penalty"):
+def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False, on_error="fallback"):
     """local_eval for sharded_evaluator / evaluate for run_generations on one GPU: native expression, upload,
     whole episodes (evaluate()'s rule), fitness as float64 numpy.  Creatures that overflow the default build's contact
     slots are re-evaluated in the wide build (evaluate.reevaluate_wide); one that overflows even that gets
-    evaluate.UNRESOLVED_FITNESS and is listed in ``evaluate.last_unresolved`` (on_error="penalty", the default: one
-    out-of-domain creature does not abort a generation; "fallback" raises SolverOverflow instead) -- or, with masked=True
+    raises SolverOverflow (on_error="fallback", the library default: Box2D has no contact cap, so there is no fitness the
+    reference would have given) or, if the caller opts in with on_error="penalty" (the EA loops do: one out-of-domain
+    creature does not abort a generation), gets evaluate.UNRESOLVED_FITNESS, a warning, and an entry in
+    ``evaluate.last_unresolved`` / ``evaluate.unresolved_log`` (one list per call) -- or, with masked=True
     (what a sharded job wants), comes back in a second array ``(fitness, unresolved)`` so that the verdict is taken after
     the job's collective."""
     from .env import BatchedModular2D
@@ -262,6 +273,8 @@ def gpu_evaluator(env=None, max_steps=None, n_threads=0, masked=False, on_error=
             return fit.cpu().numpy(), bad.cpu().numpy()
         fit = run_episode(e, cap, on_error=on_error).cpu().numpy()
         evaluate.last_unresolved = list(getattr(e, "last_unresolved", []))
+        evaluate.unresolved_log.append(list(evaluate.last_unresolved))
         return fit
     evaluate.last_unresolved = []
+    evaluate.unresolved_log = []
     return evaluate

@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 8 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+#define REM2D_ABI_VERSION 9 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
-                               7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar */
+                               7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar;
+                               9: + rem2d_build_id; worlds of tile shapes 0 and 2 are refused in one launch */
 
 enum {
     REM2D_OK = 0,
@@ -129,6 +130,11 @@ enum { REM2D_DT_F32 = 0, REM2D_DT_I32 = 1, REM2D_DT_F64 = 2 };
 #define REM2D_ERR_SOLVER_OVERFLOW 2 /* more than REM2D_SOLVER_SLOTS touching contacts on a body */
 
 int rem2d_abi_version(void);
+/* Identity of this build: the hash of the library's sources (gym_rem2d_amd/csrc/, this header) and compile flags that the
+ * builder passed in (-DREM2D_BUILD_ID), "unidentified" for a hand-made build.  The Python loader recomputes it from the sources
+ * beside the library and refuses a mismatch; bench.py prints it.  (b2World has no counterpart: pybox2d's wheel is versioned by
+ * pip, /root/reference/requirements.txt:1.) */
+const char *rem2d_build_id(void);
 const char *rem2d_last_error(void);
 /* REM2D_CONTACT_SLOTS / REM2D_SOLVER_SLOTS of this build (either pointer may be NULL) */
 int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots);
@@ -269,8 +275,9 @@ int rem2d_worlds_step_ex(rem2d_world *const *worlds, int32_t n_worlds, int32_t n
  * whose `stream` is NULL runs on `stream` itself.  Same result as rem2d_worlds_step on every group.
  * flags: REM2D_STEP_GRAPH -- capture the call's launches and fork / join edges into a hipGraph the first time and replay it
  * with one hipGraphLaunch afterwards (re-captured when a world's tiles / outputs / terrain change; ignored while kernel
- * timing is on).  A replay repeats the launches of the captured call, those of REM2D_OPT_REBALANCE included: the cadence of the
- * re-ordering is then that of the captured call, not N env-steps (a launch shape either way; no result depends on it). */
+ * timing is on).  With REM2D_OPT_REBALANCE the position of the call in the N-step cadence is part of the replay's identity, so
+ * the re-ordering launches fall on the same env-steps as without the flag (a call length that does not divide N needs
+ * N / gcd(N, n_steps) captures). */
 #define REM2D_MAX_STEP_GROUPS 16
 #define REM2D_STEP_GRAPH 1u
 typedef struct {

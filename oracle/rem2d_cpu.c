@@ -99,6 +99,7 @@ static int c_fail(int code, const char *msg) {
 }
 const char *rem2d_cpu_last_error(void) { return c_err; }
 int rem2d_cpu_abi_version(void) { return REM2D_ABI_VERSION; }
+const char *rem2d_cpu_build_id(void) { return "cpu-twin"; } /* (rem2d_build_id: the checker has no build to tell apart) */
 
 size_t rem2d_cpu_state_bytes(const rem2d_world_cfg *cfg) { return cfg_ok(cfg) ? c_make_layout(cfg).total : 0; }
 int32_t rem2d_cpu_padded_envs(const rem2d_world_cfg *cfg) { return cfg_ok(cfg) ? c_make_layout(cfg).Np : 0; }

@@ -36,7 +36,7 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 8
+    assert L.rem2d_abi_version() == 9
     assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
     # a wide world's arena is laid out for its own slot count
     big = lib.WorldCfg(4096, 8, 0, 0)
@@ -89,3 +89,32 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/librem2d.so")
     with pytest.raises(lib.Rem2dError):
         lib.lib()
+
+
+def test_build_identity(lib, tmp_path, monkeypatch):
+    """rem2d_build_id() is the hash of csrc/*, include/rem2d.h and the compile flags that build() compiled in; lib() recomputes
+    it from the sources beside the library and refuses a library built from anything else (the .so files are git-ignored but
+    travel to the GPU box: a stale one must not be tested or benched silently).  Here: a header is touched WITHOUT a rebuild."""
+    import shutil
+    for wide, flags, path in ((False, [], lib.LIB_PATH), (True, lib.WIDE_FLAGS, lib.WIDE_LIB_PATH)):
+        assert lib.build_id(wide) == lib.source_id(flags) == lib.file_build_id(path)
+        assert re.fullmatch(r"[0-9a-f]{16}", lib.build_id(wide))
+    assert lib.build_id(False) != lib.build_id(True)          # (the flags are part of the identity)
+    # a copy of the sources with one more comment line in a header, the library itself left alone
+    csrc = tmp_path / "csrc"
+    shutil.copytree(os.path.dirname(lib.SRC_PATH), str(csrc))
+    inc = tmp_path / "include"
+    inc.mkdir()
+    shutil.copy(os.path.join(lib.INCLUDE_DIR, "rem2d.h"), str(inc / "rem2d.h"))
+    with open(str(csrc / "rem2d_math.h"), "a") as f:
+        f.write("// touched\n")
+    monkeypatch.setattr(lib, "SRC_PATH", str(csrc / "rem2d.hip"))
+    monkeypatch.setattr(lib, "INCLUDE_DIR", str(inc))
+    monkeypatch.setattr(lib, "_lib", None)
+    assert lib.source_id() != lib.file_build_id(lib.LIB_PATH)
+    with pytest.raises(lib.Rem2dError, match="stale"):
+        lib.lib()
+    # an experiment's variant build named through REM2D_LIB_PATH is exempt (tools/build_variant.sh)
+    monkeypatch.setenv("REM2D_LIB_PATH", lib.LIB_PATH)
+    assert lib.lib().rem2d_abi_version() == 9
+    monkeypatch.setattr(lib, "_lib", None)

@@ -138,12 +138,17 @@ def _overflow_worker(rank, world, port, out_dir):
         evaluate_population_sharded(n_total, local_eval, on_error="raise")
     except SolverOverflow as e:      # raised AFTER the collective, on every rank, with the global index
         verdict = "overflow %s" % e.indices
-    # the default: the defined penalty on every rank alike, the job goes on
+    # the library default raises too; an EA loop opts in to the defined penalty: on every rank alike, the job goes on
+    try:
+        evaluate_population_sharded(n_total, local_eval)
+        verdict += " (default completed)"
+    except SolverOverflow:
+        pass
     import warnings
     from gym_rem2d_amd.evaluate import UNRESOLVED_FITNESS
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        fit = evaluate_population_sharded(n_total, local_eval)
+        fit = evaluate_population_sharded(n_total, local_eval, on_error="penalty")
     want = torch.arange(n_total, dtype=torch.float64)
     want[7] = UNRESOLVED_FITNESS
     assert torch.equal(fit, want) and evaluate_population_sharded.last_unresolved == [7]
@@ -161,11 +166,12 @@ def _overflow_worker(rank, world, port, out_dir):
         verdict += " | completed"
     except SolverOverflow as e:
         verdict += " | overflow %s" % e.indices
-    ev = sharded_evaluator(block_eval)
+    ev = sharded_evaluator(block_eval, on_error="penalty")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         f2 = ev(pop)
     assert ev.last_unresolved == [5] and f2[5] == UNRESOLVED_FITNESS and (np.delete(f2, 5) == 1.0).all()
+    assert ev.unresolved_log == [[5]]   # (one entry per call: a long run keeps every generation's list)
     # and a clean job still returns the gathered fitness
     fit = evaluate_population_sharded(n_total, lambda lo, hi: (torch.arange(lo, hi, dtype=torch.float64),
                                                                torch.zeros(hi - lo, dtype=torch.bool)))
@@ -180,9 +186,10 @@ def _overflow_worker(rank, world, port, out_dir):
 def test_sharded_job_with_an_overflowing_creature_completes_gloo(tmp_path):
     """A rank whose shard holds a creature without a valid fitness (it overflowed even the wide build) must not raise
     before the job's collective -- the other ranks would wait in the all-gather for ever.  The mask rides in the fitness
-    all-gather; afterwards every rank holds the same verdict: by default the creature gets evaluate.UNRESOLVED_FITNESS on
-    every rank alike and the job goes on (an EA generation is not aborted by one out-of-domain creature); with
-    on_error="raise" EVERY rank raises SolverOverflow, naming the population index."""
+    all-gather; afterwards every rank holds the same verdict: with on_error="raise" (the library default: the reference has no
+    contact cap and would have produced a fitness) EVERY rank raises SolverOverflow, naming the population index; with
+    on_error="penalty" (what an EA loop opts into, so that one out-of-domain creature does not abort a generation) the creature
+    gets evaluate.UNRESOLVED_FITNESS on every rank alike and the job goes on."""
     world, port = 2, _free_port()
     mp.spawn(_overflow_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):

@@ -708,6 +708,33 @@ def test_tile_shape_per_world_and_mixed_in_one_launch(gpu, oracle, rough_terrain
             assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
             assert int(w.view("err").max()) == 0
             w.close()
+    # the one unsound mix: a tile planned for shape 2 (<= 192 joints IN ALL, placed flexibly) may hold more than 64 joints in one
+    # schedule phase, which the static four-set kernel that a shape-0 world pulls the launch to cannot take -- refused, in every
+    # entry point that merges worlds, instead of dropping joints (ABI v9)
+    ws = []
+    for m, sh in zip(morphs, (2, 3, 0)):
+        w = gpu(m.n_envs, m.lanes, flags=_lib.FLAG_CONTINUOUS)
+        w.set_terrain(rough_terrain)
+        w.reset(m, tile_shape=0 if m.lanes > (256, 128, 192, 64, 128)[sh] else sh)
+        ws.append(w)
+    if sorted(w.tile_shape for w in ws) == [0, 2, 3]:
+        arr = (C.c_void_p * len(ws))(*[w.h for w in ws])
+        with pytest.raises(_lib.Rem2dError, match="shapes 0 and 2"):
+            _lib.check(_lib.lib().rem2d_worlds_step(arr, len(ws), 1, ws[0]._stream()))
+        sg = (_lib.StepGroup * 1)()
+        sg[0].worlds, sg[0].n_worlds, sg[0].stream = arr, len(ws), None
+        with pytest.raises(_lib.Rem2dError, match="shapes 0 and 2"):
+            _lib.check(_lib.lib().rem2d_groups_step(sg, 1, 1, ws[0]._stream(), 0))
+        with pytest.raises(_lib.Rem2dError, match="shapes 0 and 2"):
+            _lib.check(_lib.lib().rem2d_worlds_launch_info(arr, len(ws), None, None))
+        # ... and the same three worlds step fine as two launches
+        _lib.check(_lib.lib().rem2d_worlds_step(arr, 2, 5, ws[0]._stream()))
+        _lib.check(_lib.lib().rem2d_world_step(ws[2].h, 5, ws[0]._stream()))
+        for w, m in zip(ws, morphs):
+            ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), m.as_dict(), 5, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+            assert np.array_equal(w.bodies(), ref["bodies"]) and int(w.view("err").max()) == 0
+    for w in ws:
+        w.close()
     w = gpu(morphs[0].n_envs, morphs[0].lanes)
     with pytest.raises(_lib.Rem2dError, match="tile shape"):
         _lib.check(_lib.lib().rem2d_world_set_tile_shape(w.h, 5))
