@@ -329,10 +329,10 @@ def launch_ranks(args):
 METRIC = "env steps/sec (whole node) at 65 536 parallel creatures; 1/2/4/8-GPU scaling"   # BASELINE.json's, verbatim
 
 
-def make_env(morphs, dev, hard, flat, discrete):
+def make_env(morphs, dev, hard, flat, discrete, wide=False):
     from gym_rem2d_amd import _lib
     from gym_rem2d_amd.env import BatchedModular2D
-    env = BatchedModular2D(flat=flat, hardcore=hard, seed=4, device=dev, flags=0 if discrete else _lib.FLAG_CONTINUOUS)
+    env = BatchedModular2D(flat=flat, hardcore=hard, seed=4, device=dev, flags=0 if discrete else _lib.FLAG_CONTINUOUS, wide=wide)
     batches, lo = [], 0
     for m in morphs:
         batches.append((m, list(range(lo, lo + m.n_envs))))
@@ -490,6 +490,13 @@ def main():
         if world > 1:
             all_gather_fitness(fit.to(cdev), per_rank * world)   # the job's only collective
 
+    # predicted cost of every rank's shard (bodies to step; outside any timed region -- measurement plumbing, not the job's
+    # collective): the line shows how even the cut is
+    my_cost = int(sum(int(m.n_bodies.sum()) for m in morphs)) if not single else 0
+    shard_cost = [my_cost]
+    if world > 1:
+        shard_cost = [None] * world
+        dist.all_gather_object(shard_cost, my_cost)
     if generation:
         args.settle = args.warmup = 0
     run(args.settle)
@@ -587,13 +594,40 @@ def main():
                              "timed_region_s": float(sum(b2)), "step_groups": max(1, len(env2.groups)),
                              "tile_shape": env2._tile_shape_used, "solver_errors": int(env2.errors().max())}
             env2.close()
+        # the headline workload once more in the labelled TOLERANCE MODE (librem2d_fma.so: the same source with
+        # -ffp-contract=fast; NOT bit-exact -- tests/test_parity_gpu.py::test_fma_tolerance_mode_transition_parity states what it
+        # keeps: integer state in >= 99.98 % of the transitions, poses within 1e-5 + 1e-4 |x| in >= 99.95 %).  A secondary figure:
+        # the strict build is the headline and the only thing the digests guard.
+        try:
+            env3 = make_env(morphs, dev, hard, flat, False, wide="fma")
+            run3 = stepper(env3, spl)
+            run3(args.settle)
+            run3(20)
+            b3 = timed_blocks(run3, 100, 0.5, 50, sync, reduce_max)
+            d3 = float(np.median(b3))
+            from gym_rem2d_amd import _lib as _l3
+            secondary["fma_tolerance_mode"] = {
+                "value": total * 100 / d3, "unit": "env-steps/s", "ms_per_step": d3 / 100 * 1e3,
+                "workload": workload_desc + " -- TOLERANCE MODE (-ffp-contract=fast build, not bit-exact; validated transition by "
+                                            "transition against the strict build)", "build_id": _l3.build_id("fma"),
+                "steps_per_block": 100, "blocks_ms": [round(x * 1e3, 3) for x in b3], "timed_region_s": float(sum(b3)),
+                "step_groups": max(1, len(env3.groups)), "tile_shape": env3._tile_shape_used,
+                "solver_errors": int(env3.errors().max())}
+            env3.close()
+        except Exception as e:   # (a missing librem2d_fma.so must not take the headline down with it)
+            secondary["fma_tolerance_mode"] = {"error": str(e)}
 
     if rank == 0:
+        from gym_rem2d_amd import _lib as _l
+        _build_id = _l.build_id()
         out = {
             "metric": METRIC,
             "value": total * args.steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "world_size": world,                                  # ranks that took part in the job's collective
+            "backend": backend if world > 1 else None,            # "nccl" = RCCL over xGMI, "gloo" = ranks sharing one GPU
+            "build_id": _build_id,
             "creatures_total": total,   # the population `value` is quoted on (weak scaling: 65 536 PER GPU, see `scaling`)
             "steps": args.steps,
             "warmup": args.warmup,
@@ -615,6 +649,7 @@ def main():
                        "parallelism": "population sharded over %d rank(s), one per GPU, no per-step collective; one fp64 "
                                       "fitness all-gather per block (%s)" % (world, backend if world > 1 else "none at 1 rank"),
                        "ranks_share_one_gpu": bool(world > 1 and n_dev < world),
+                       "shard_cost_bodies": shard_cost,   # per rank: bodies in its shard (the static cost key of evaluate.shard_balanced)
                        "merged_launch": bool(merged), "step_groups": n_groups, "hip_graph": bool(env.use_graph),
                        # every block = exactly `steps` env-steps between barrier + synchronize; value = median block
                        "blocks": len(blocks), "blocks_ms": [round(x * 1e3, 3) for x in blocks],

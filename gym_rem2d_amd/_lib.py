@@ -12,6 +12,11 @@ LIB_PATH = os.environ.get("REM2D_LIB_PATH") or os.path.join(_HERE, "librem2d.so"
 # the same source built with -DREM2D_WIDE (32 pair slots / 12 solver slots per body): where the creatures that overflowed the
 # default build's slots are re-evaluated (evaluate.run_episode) -- Box2D itself has no cap (Modular2DEnv.py:634)
 WIDE_LIB_PATH = os.environ.get("REM2D_WIDE_LIB_PATH") or os.path.join(_HERE, "librem2d_wide.so")
+# the same source built with -ffp-contract=fast: the compiler fuses a * b + c into v_fma_f32 wherever it likes.  NOT the bit-exact
+# product: a labelled TOLERANCE MODE (north_star: "within a stated fp32 tolerance on positions/velocities") that
+# tests/test_parity_gpu.py validates transition by transition against the strict build and bench.py reports as a secondary line
+# beside the strict headline.  Selected with wide="fma" wherever a `wide` argument is taken.
+FMA_LIB_PATH = os.environ.get("REM2D_FMA_LIB_PATH") or os.path.join(_HERE, "librem2d_fma.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "rem2d.hip")
 
 FLAG_CONTINUOUS = 1
@@ -120,6 +125,15 @@ class Rem2dError(RuntimeError):
 # operation separately rounded (what the bit-exact parity rests on).
 BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared"]
 WIDE_FLAGS = ["-DREM2D_WIDE=1"]
+FMA_FLAGS = ["-ffp-contract=fast"]   # (the later -ffp-contract wins over BUILD_FLAGS')
+
+
+def _variant(wide):
+    """(path, extra flags, name of the overriding environment variable) of a build: False the default, True the wide-slot
+    build, "fma" the tolerance-mode build."""
+    if wide == "fma":
+        return FMA_LIB_PATH, FMA_FLAGS, "REM2D_FMA_LIB_PATH"
+    return (WIDE_LIB_PATH, WIDE_FLAGS, "REM2D_WIDE_LIB_PATH") if wide else (LIB_PATH, [], "REM2D_LIB_PATH")
 INCLUDE_DIR = os.path.join(_ROOT, "include")
 _ID_MARKER = b"REM2D_BUILD_ID="
 
@@ -156,11 +170,11 @@ def file_build_id(path):
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so and (-DREM2D_WIDE) librem2d_wide.so (hipcc
-    cross-compiles without a GPU; the two compile side by side).  A library is rebuilt when the id compiled into it differs
-    from source_id() -- the hash of the sources and flags, not a file time."""
+    """Compile csrc/rem2d.hip for gfx950 into gym_rem2d_amd/librem2d.so, (-DREM2D_WIDE) librem2d_wide.so and (-ffp-contract=fast,
+    the labelled tolerance mode) librem2d_fma.so -- hipcc cross-compiles without a GPU; the three compile side by side.  A
+    library is rebuilt when the id compiled into it differs from source_id(): the hash of the sources and flags, not a file time."""
     procs = []
-    for path, extra in ((LIB_PATH, []), (WIDE_LIB_PATH, WIDE_FLAGS)):
+    for path, extra in ((LIB_PATH, []), (WIDE_LIB_PATH, WIDE_FLAGS), (FMA_LIB_PATH, FMA_FLAGS)):
         want = source_id(extra)
         if not force and file_build_id(path) == want:
             continue
@@ -197,9 +211,9 @@ def lib(wide=False):
     global _lib
     if not wide and _lib is not None:
         return _lib
-    if wide and True in _libs:
-        return _libs[True]
-    path = WIDE_LIB_PATH if wide else LIB_PATH
+    if wide and wide in _libs:
+        return _libs[wide]
+    path, flags, override_var = _variant(wide)
     # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).
     # Import torch first so that librem2d.so binds to the runtime torch initialises -- two runtimes
     # in one process fail with "no ROCm-capable device is detected".
@@ -258,13 +272,13 @@ def lib(wide=False):
     L.rem2d_build_id.restype = C.c_char_p
     # the library must have been built from the sources beside it (REM2D_LIB_PATH / REM2D_WIDE_LIB_PATH name an experiment's
     # variant build on purpose: tools/build_variant.sh, exempt)
-    overridden = os.environ.get("REM2D_WIDE_LIB_PATH" if wide else "REM2D_LIB_PATH")
-    have, want = L.rem2d_build_id().decode(), source_id(WIDE_FLAGS if wide else [])
+    overridden = os.environ.get(override_var)
+    have, want = L.rem2d_build_id().decode(), source_id(flags)
     if not overridden and have != want:
         raise Rem2dError("%s is stale: built from sources with id %s, the sources here have id %s -- rebuild it with "
                          "`python -c 'import __graft_entry__ as g; g.build()'`" % (os.path.basename(path), have, want))
     if wide:
-        _libs[True] = L
+        _libs[wide] = L
     else:
         _lib = L
     return L

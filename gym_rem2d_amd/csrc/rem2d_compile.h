@@ -303,7 +303,7 @@ extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tre
                                      double terrain_height, int32_t lanes, const rem2d_morph *out, int32_t *n_bodies,
                                      int32_t n_threads) {
     using namespace rem2d_host;
-    if (!G || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (!G || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument"); // (out == NULL: the body counts only)
     if (G->n_types <= 0 || G->n_types > 64) return fail(REM2D_E_INVALID, "n_types must be 1..64");
     if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
     const int n = G->n, T = G->n_types;
@@ -332,7 +332,7 @@ extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tre
             Creature cr;
             build_creature(g, nodes, nNodes, terrain_height, cr);
             if (ex.overflow || cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
-            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
+            if (out) write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper); // (out == NULL: count only)
             n_bodies[e] = cr.nBodies;
         }
     };
@@ -355,7 +355,7 @@ extern "C" int rem2d_compile_lsystem(const rem2d_lsystem_genomes *G, int32_t tre
 extern "C" int rem2d_compile_trees(const rem2d_tree_batch *B, double terrain_height, int32_t lanes, const rem2d_morph *out,
                                    int32_t *n_bodies, int32_t n_threads) {
     using namespace rem2d_host;
-    if (!B || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (!B || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument"); // (out == NULL: the body counts only)
     if (B->max_nodes <= 0 || B->max_nodes > MAXN) return fail(REM2D_E_INVALID, "max_nodes must be 1..64");
     if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
     const int n = B->n, M = B->max_nodes;
@@ -387,7 +387,7 @@ extern "C" int rem2d_compile_trees(const rem2d_tree_batch *B, double terrain_hei
             Creature cr;
             build_creature(g, nodes, nNodes, terrain_height, cr);
             if (cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
-            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
+            if (out) write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper); // (out == NULL: count only)
             n_bodies[e] = cr.nBodies;
         }
     };
@@ -552,7 +552,7 @@ struct NetExpander {
 extern "C" int rem2d_compile_network(const rem2d_network_genomes *G, int32_t tree_depth, double terrain_height, int32_t lanes,
                                      const rem2d_morph *out, int32_t *n_bodies, int32_t n_threads) {
     using namespace rem2d_host;
-    if (!G || !out || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument");
+    if (!G || !n_bodies) return fail(REM2D_E_INVALID, "NULL argument"); // (out == NULL: the body counts only)
     if (G->n_types <= 0 || G->n_types > 64) return fail(REM2D_E_INVALID, "n_types must be 1..64");
     if (G->n_hidden <= 0 || G->n_hidden > 64) return fail(REM2D_E_INVALID, "n_hidden must be 1..64");
     if (lanes <= 0 || lanes > MAXN) return fail(REM2D_E_INVALID, "lanes must be 1..64");
@@ -589,7 +589,7 @@ extern "C" int rem2d_compile_network(const rem2d_network_genomes *G, int32_t tre
             Creature cr;
             build_creature(g, nodes, nNodes, terrain_height, cr);
             if (ex.overflow || cr.overflow || cr.nBodies > lanes) { status[tid] = 1; n_bodies[e] = -1; continue; }
-            write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper);
+            if (out) write_creature(out, (size_t)e * lanes, lanes, cr, nodes, g, lower, upper); // (out == NULL: count only)
             n_bodies[e] = cr.nBodies;
         }
     };

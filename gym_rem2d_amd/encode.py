@@ -143,6 +143,27 @@ def compile_lsystem_arrays(arrays, tree_depth, max_modules, lanes, n_threads=0):
     return m
 
 
+def count_lsystem_bodies(arrays, tree_depth, max_modules, n_threads=0):
+    """rem2d_compile_lsystem with out = NULL: the body count of every genome's creature (expression + create_robot's skip rules,
+    nothing written) -- int32 [n].  A static cost key: lanes, joint rounds and solver work all grow with it."""
+    import ctypes as C
+    from . import _lib
+    from .compiler import TERRAIN_HEIGHT
+    n, T = int(arrays["mod_shape"].shape[0]), int(arrays["mod_shape"].shape[1])
+    G = _lib.LsystemGenomes()
+    G.n, G.n_types = n, T
+    keep = []
+    for k in ("mod_shape", "mod_width", "mod_height", "mod_radius", "mod_angle", "mod_torque", "ctl_amp", "ctl_phase",
+              "ctl_freq", "ctl_offset", "rule_n", "rule_site", "rule_ref"):
+        v = np.ascontiguousarray(arrays[k])
+        keep.append(v)
+        setattr(G, k, v.ctypes.data_as(C.c_void_p))
+    nb = np.zeros(n, dtype=np.int32)
+    _lib.check(_lib.lib().rem2d_compile_lsystem(C.byref(G), int(tree_depth), int(max_modules), float(TERRAIN_HEIGHT), 64, None,
+                                                nb.ctypes.data_as(C.c_void_p), int(n_threads)))
+    return nb
+
+
 def batches_from_compiled(m):
     """Split a wide compiled batch into per-lane-count buckets, sorted like encode_population."""
     K = m.lanes

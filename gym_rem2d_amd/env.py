@@ -83,7 +83,7 @@ class BatchedModular2D:
         # wide: the worlds live in librem2d_wide.so (32 pair slots / 12 solver slots per body; evaluate.run_episode re-runs
         # there the creatures that overflowed the default build's slots)
         from . import _lib
-        self.wide = bool(wide)
+        self.wide = wide if wide == "fma" else bool(wide)   # ("fma": the labelled -ffp-contract=fast tolerance mode, not bit-exact)
         self.hardcore, self.flat = hardcore, flat
         self.flags = _lib.FLAG_CONTINUOUS if flags is None else flags
         self.device = device

@@ -242,14 +242,40 @@ def shard_range(n, rank, world_size):
     return lo, min(n, lo + per)
 
 
-def all_gather_fitness(local, n_total, group=None, flags=None):
+def shard_balanced(cost, world_size):
+    """Cost-balanced shards (what replaces the dynamic balancing of REM2D_main.py:256-262's pool.map): the individuals in
+    descending order of a static cost key (ties: population order -- every rank computes the same deal) are dealt snake-wise
+    over the ranks, 0 .. W-1, W-1 .. 0, 0 ..  Returns int64 [W][ceil(n / W)]: row r = the population indices of rank r in the order
+    it evaluates them, padded with -1.  Episodes end early for creatures that fall or get caught (Modular2DEnv.py:642-649), which
+    no static key sees; what the key evens out is the per-step cost (lanes, joint rounds, solver work: all grow with the bodies)."""
+    cost = np.asarray(cost)
+    n, W = len(cost), int(world_size)
+    per = math.ceil(n / W) if n else 0
+    order = np.argsort(-cost.astype(np.int64), kind="stable")
+    out = np.full((W, per), -1, dtype=np.int64)
+    k = np.arange(n)
+    rnd, pos = k // W, k % W
+    rank = np.where(rnd % 2 == 0, pos, W - 1 - pos)
+    out[rank, rnd] = order
+    return out
+
+
+def shard_costs(cost, index):
+    """Predicted cost of every rank under the deal `index` (shard_balanced): float64 [W]."""
+    cost = np.asarray(cost, dtype=np.float64)
+    return np.array([cost[row[row >= 0]].sum() for row in np.asarray(index)])
+
+
+def all_gather_fitness(local, n_total, group=None, flags=None, index=None):
     """One all_gather of float64 fitness scalars: [per] -> [n_total] on every rank.  `local` is padded to ceil(n/W) so
     that the collective is a single equal-sized all_gather_into_tensor.  float64 like the reference's python floats
     (REM2D_main.py:372-375 compares ``reward + (10000 - i) / 10000`` in doubles): a sharded and a single-GPU run return
     the same values, so tournament winners cannot depend on the world size.  8 MiB at 1 M individuals.
     flags: optional bool / int [per] mask of the rank's creatures without a valid fitness (run_episode_masked); it rides
     in the same collective as a second column and the call returns (fitness [n_total], flags [n_total] bool) -- every
-    rank learns about every rank's failures AFTER the collective and can raise in step."""
+    rank learns about every rank's failures AFTER the collective and can raise in step.
+    index: the deal of shard_balanced (int64 [W][per], -1 padding) when the ranks hold dealt instead of contiguous shards:
+    rank r's j-th value belongs to individual index[r][j]; the result is in population order either way."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = math.ceil(n_total / world)
@@ -261,15 +287,29 @@ def all_gather_fitness(local, n_total, group=None, flags=None):
     out = torch.empty(world * cols * per, dtype=torch.float64, device=local.device)
     dist.all_gather_into_tensor(out, buf.reshape(-1), group=group)
     out = out.view(world, cols, per)
-    fit = out[:, 0].reshape(-1)[:n_total]
+    if index is None:
+        fit = out[:, 0].reshape(-1)[:n_total]
+        bad = out[:, 1].reshape(-1)[:n_total] != 0 if flags is not None else None
+    else:   # dealt shards: scatter back to population order
+        idx = torch.as_tensor(np.asarray(index), dtype=torch.long, device=out.device).reshape(-1)
+        keep = idx >= 0
+        fit = torch.zeros(n_total, dtype=torch.float64, device=out.device)
+        fit[idx[keep]] = out[:, 0].reshape(-1)[keep]
+        bad = None
+        if flags is not None:
+            bad = torch.zeros(n_total, dtype=torch.bool, device=out.device)
+            bad[idx[keep]] = out[:, 1].reshape(-1)[keep] != 0
     if flags is None:
         return fit
-    return fit, out[:, 1].reshape(-1)[:n_total] != 0
+    return fit, bad
 
 
-def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on_error="raise"):
+def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on_error="raise", cost=None):
     """Shard [0, n_total) over the job's ranks, evaluate the local block with
     ``local_eval(lo, hi) -> tensor[hi-lo]`` (or ``-> (tensor, unresolved mask)``, run_episode_masked) and all-gather.
+    cost (optional, [n_total], the same on every rank): a static cost key per individual -- the shards are then dealt by
+    shard_balanced instead of cut contiguously, ``local_eval(indices)`` gets the rank's population indices (int64 array) and
+    ``evaluate_population_sharded.last_shard_cost`` holds the predicted cost per rank; the result is in population order.
     Returns fitness[n_total] (float64).  The mask rides in the same collective, so every rank learns about every rank's
     unresolved creatures AFTER it: with on_error="raise" (the library default -- the reference has no contact cap and would
     have produced a fitness) every rank raises SolverOverflow in step; with "penalty" (an EA loop's opt-in) they get
@@ -277,15 +317,21 @@ def evaluate_population_sharded(n_total, local_eval, group=None, device=None, on
     the job goes on."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_range(n_total, rank, world)
-    local = local_eval(lo, hi)
+    index = None
+    if cost is not None:
+        index = shard_balanced(cost, world)
+        evaluate_population_sharded.last_shard_cost = shard_costs(cost, index)
+        local = local_eval(index[rank][index[rank] >= 0])
+    else:
+        lo, hi = shard_range(n_total, rank, world)
+        local = local_eval(lo, hi)
     mask = None
     if isinstance(local, tuple):
         local, mask = local
     local = torch.as_tensor(local, dtype=torch.float64, device=device if device is not None else None)
     if mask is None:
         mask = torch.zeros(local.numel(), dtype=torch.bool, device=local.device)
-    fit, bad = all_gather_fitness(local, n_total, group, flags=torch.as_tensor(mask, device=local.device))
+    fit, bad = all_gather_fitness(local, n_total, group, flags=torch.as_tensor(mask, device=local.device), index=index)
     evaluate_population_sharded.last_unresolved = []
     if bool(bad.any()):
         if on_error != "penalty":

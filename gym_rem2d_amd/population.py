@@ -171,6 +171,11 @@ class LSystemPopulation:
             a["rule_n"][e, t] = k - 1
 
     # ------------------------------------------------------------------ expression
+    def body_counts(self, n_threads=0):
+        """Bodies of every individual's creature (native expression, nothing else computed): the static cost key of
+        evaluate.shard_balanced."""
+        return encode.count_lsystem_bodies(self.a, self.tree_depth, self.max_modules, n_threads)
+
     def compile(self, n_threads=0):
         """Native genotype -> phenotype -> per-lane-count Morphology batches (BatchedModular2D._upload input)."""
         lanes = 64 if self.max_modules + 1 > 32 else encode.lanes_for(self.max_modules + 1)
@@ -201,12 +206,18 @@ def run_generations(pop, n_generations, evaluate, rng, morph_rate=0.01, rate=0.0
     return pop, fit, history
 
 
-def sharded_evaluator(local_eval, group=None, device=None, on_error="raise"):
+def sharded_evaluator(local_eval, group=None, device=None, on_error="raise", balance=True, n_threads=0):
     """evaluate(population) for a torch.distributed job (one process per GPU): every rank holds the whole
     population as arrays (selection and mutation are replicated from a shared seed, so no genome ever crosses a
     rank boundary), expresses and evaluates only its contiguous block ``[lo, hi)`` with
     ``local_eval(LSystemPopulation block) -> fitness[hi-lo]`` and the ranks exchange one all-gather of float64
     fitness (REM2D_main.py:256-267 pool.map).
+
+    balance (default): the reference's pool balances dynamically (pool.map hands out chunks as workers finish); a static
+    contiguous cut does not, and a generation ends with its slowest rank.  Every rank therefore computes the same deal from the
+    arrays it holds anyway -- the individuals in descending order of body count (a native expression pass, population.body_counts)
+    dealt snake-wise over the ranks, evaluate.shard_balanced -- and the fitness comes back in population order through the same
+    single all-gather.  ``evaluate.last_shard_cost`` = the predicted cost (bodies) per rank.  balance=False: contiguous blocks.
 
     on_error: what to do about creatures without a valid fitness (beyond even the wide build's contact slots -- Box2D has
     no such cap, so the reference would have produced a number).  "raise" (the library default): every rank raises
@@ -215,12 +226,20 @@ def sharded_evaluator(local_eval, group=None, device=None, on_error="raise"):
     call in ``evaluate.unresolved_log`` (a list that grows by one entry per call: a long run cannot lose them)."""
     import torch
     import torch.distributed as dist
-    from .evaluate import all_gather_fitness, shard_range
+    from .evaluate import all_gather_fitness, shard_balanced, shard_costs, shard_range
 
     def evaluate(pop):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        lo, hi = shard_range(len(pop), rank, world)
-        local = local_eval(pop.select(np.arange(lo, hi))) if hi > lo else np.zeros(0, dtype=np.float64)
+        index = None
+        if balance:
+            cost = pop.body_counts(n_threads)
+            index = shard_balanced(cost, world)
+            mine = index[rank][index[rank] >= 0]
+            evaluate.last_shard_cost = shard_costs(cost, index)
+        else:
+            lo, hi = shard_range(len(pop), rank, world)
+            mine = np.arange(lo, hi)
+        local = local_eval(pop.select(mine)) if len(mine) else np.zeros(0, dtype=np.float64)
         mask = None
         if isinstance(local, tuple):     # (fitness, unresolved mask): gpu_evaluator(masked=True)
             local, mask = local
@@ -230,7 +249,7 @@ def sharded_evaluator(local_eval, group=None, device=None, on_error="raise"):
         # before the collective (the others would wait in it for ever).  After it every rank holds the same mask: the
         # creatures get the defined penalty on every rank alike (on_error="penalty": the generation goes on, the indices
         # are kept in evaluate.last_unresolved) or every rank raises in step (on_error="raise")
-        fit, bad = all_gather_fitness(local, len(pop), group, flags=mask.to(local.device))
+        fit, bad = all_gather_fitness(local, len(pop), group, flags=mask.to(local.device), index=index)
         evaluate.last_unresolved = []
         if bool(bad.any()):
             from .evaluate import SolverOverflow, apply_penalty
@@ -243,6 +262,7 @@ def sharded_evaluator(local_eval, group=None, device=None, on_error="raise"):
         return fit.cpu().numpy().astype(np.float64)
     evaluate.last_unresolved = []
     evaluate.unresolved_log = []
+    evaluate.last_shard_cost = None
     return evaluate
 
 

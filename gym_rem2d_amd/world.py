@@ -19,14 +19,15 @@ _DTYPES = {0: torch.float32, 1: torch.int32, 2: torch.float64}
 
 class BatchedWorld:
     def __init__(self, n_envs, lanes, flags=0, device=None, wide=False, options=None):
-        """wide: use librem2d_wide.so (32 pair slots / 12 solver slots per body instead of 24 / 6).  options: launch options
+        """wide: True = librem2d_wide.so (32 pair slots / 12 solver slots per body instead of 24 / 6); "fma" = librem2d_fma.so, the
+        -ffp-contract=fast tolerance mode (NOT bit-exact: validated within a stated tolerance, never the default).  options: launch options
         {name: value} (``_lib.OPTIONS``, rem2d_world_set_option) -- launch shapes and scheduling hints, never results;
         on top of the REM2D_* experiment overrides of the environment (``_lib.env_options``)."""
         if not torch.cuda.is_available():
             raise _lib.Rem2dError("gym_rem2d_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.n_envs, self.lanes, self.flags = int(n_envs), int(lanes), int(flags)
-        self.wide = bool(wide)
+        self.wide = wide if wide == "fma" else bool(wide)   # ("fma": the labelled tolerance-mode build, _lib.FMA_LIB_PATH)
         L = self.L = _lib.lib(self.wide)
         self.contact_slots = _lib.capacity(self.wide)[0]
         self.cfg = _lib.WorldCfg(self.n_envs, self.lanes, self.flags, self.device.index or 0)

@@ -307,7 +307,9 @@ typedef struct rem2d_lsystem_genomes {
 } rem2d_lsystem_genomes;
 /* out: host arrays of n*lanes elements each (same fields as rem2d_morph, written, not read);
  * n_bodies[n]: bodies of every creature.  Fails (and marks the creature with n_bodies = -1) if a creature
- * needs more than `lanes` lanes.  max_modules <= 63.  n_threads <= 0: all hardware threads. */
+ * needs more than `lanes` lanes.  max_modules <= 63.  n_threads <= 0: all hardware threads.
+ * out == NULL (all three compilers): expression and create_robot's rules only -- n_bodies is filled, nothing else is written
+ * (the static cost key by which a sharded job deals its individuals to the ranks, gym_rem2d_amd.evaluate.shard_balanced). */
 int rem2d_compile_lsystem(const rem2d_lsystem_genomes *genomes, int32_t tree_depth, int32_t max_modules,
                           double terrain_height, int32_t lanes, const rem2d_morph *out, int32_t *n_bodies,
                           int32_t n_threads);
