@@ -111,6 +111,19 @@ class NetworkGenomes(C.Structure):
                                              "ctl_max_offset", "ctl_max_freq")])
 
 
+class TreePopulation(C.Structure):
+    """rem2d_tree_population (include/rem2d.h): host pointers, [n][max_nodes], mutated in place by rem2d_mutate_trees."""
+    _fields_ = ([("n", C.c_int32), ("max_nodes", C.c_int32)]
+                + [(k, C.c_void_p) for k in ("node_count", "parent", "site", "shape", "width", "height", "radius", "angle", "torque",
+                                             "ctl_amp", "ctl_phase", "ctl_freq", "ctl_offset")]
+                + [(k, C.c_int32) for k in ("max_modules", "max_depth", "n_box", "n_circle")]
+                + [(k, C.c_double) for k in ("proto_box_width", "proto_box_height", "proto_circle_radius", "proto_angle",
+                                             "proto_torque", "box_min_width", "box_max_width", "box_min_height", "box_max_height",
+                                             "box_min_angle", "box_max_angle", "circle_min_radius", "circle_max_radius",
+                                             "circle_min_angle", "circle_max_angle", "ctl_max_amp", "ctl_max_phase",
+                                             "ctl_max_offset", "ctl_max_freq")])
+
+
 class StepGroup(C.Structure):
     """rem2d_step_group (include/rem2d.h)."""
     _fields_ = [("worlds", C.POINTER(C.c_void_p)), ("n_worlds", C.c_int32), ("stream", C.c_void_p)]
@@ -260,6 +273,7 @@ def lib(wide=False):
     L.rem2d_compile_trees.argtypes = [C.POINTER(TreeBatch), C.c_double, C.c_int32, C.POINTER(Morph), C.c_void_p, C.c_int32]
     L.rem2d_compile_network.argtypes = [C.POINTER(NetworkGenomes), C.c_int32, C.c_double, C.c_int32, C.POINTER(Morph),
                                         C.c_void_p, C.c_int32]
+    L.rem2d_mutate_trees.argtypes = [C.POINTER(TreePopulation), C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32]
     L.rem2d_tree_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_selftest_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.rem2d_world_field.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),

@@ -605,4 +605,214 @@ extern "C" int rem2d_compile_network(const rem2d_network_genomes *G, int32_t tre
     return REM2D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// DirectEncoding.mutate (Encodings/Direct_Encoding.py:82-139) for a whole array population, in place, native and
+// multi-threaded (round 5; REM2D_main.py:280-298 mutates every offspring of every generation: at 1 M individuals the numpy
+// form of gym_rem2d_amd.population.DirectPopulation costs ~8 s per generation, this ~0.1 s).  One individual after the other
+// per thread, the reference's algorithm statement by statement -- the children walk with its list-iterator semantics (the
+// sibling that slides into a removed child's slot is skipped; a hit on a child of the ROOT removes nothing, but the child is
+// not descended into), countModules() recounts, the growth loop over the free sites with the same iterator semantics, then
+// module.mutate / limitWH and controller.mutate / minMax of every visited node.  Not the reference's random stream (python's
+// Mersenne twister): a xoshiro256** per individual seeded from (seed, individual) -- the same distributions, the same result
+// whatever the thread count.  Left out: the order in which freed sites are re-appended to availableConnections (here always
+// left, right, top).
+// ---------------------------------------------------------------------------------------------------
+namespace rem2d_host {
+
+struct Rng {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t &x) {
+        uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    Rng(uint64_t seed, uint64_t stream) {
+        uint64_t x = seed ^ (stream * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull);
+        for (int i = 0; i < 4; ++i) s[i] = splitmix(x);
+    }
+    static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uniform() { return (double)(next() >> 11) * 0x1.0p-53; }            // [0, 1)
+    double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
+    int randint(int n) { return (int)(uniform() * n); }                        // 0 .. n - 1
+    double gauss(double mu, double sigma) {                                     // Marsaglia's polar method
+        double u, v, q;
+        do { u = 2.0 * uniform() - 1.0; v = 2.0 * uniform() - 1.0; q = u * u + v * v; } while (q >= 1.0 || q == 0.0);
+        return mu + sigma * u * std::sqrt(-2.0 * std::log(q) / q);
+    }
+};
+
+struct MutNode {
+    int shape, site, nChild, child[3];
+    bool freeSite[3];
+    double width, height, radius, angle, torque, amp, phase, freq, offset;
+};
+struct TreeMutator {
+    const rem2d_tree_population &P;
+    Rng rng;
+    MutNode nd[2 * MAXN];
+    int nNodes;          // pool entries handed out
+    int nModules;        // countModules()
+    double morph, rate, sigma;
+    TreeMutator(const rem2d_tree_population &p, uint64_t seed, uint64_t e, double m, double r, double sg)
+        : P(p), rng(seed, e), nNodes(0), nModules(0), morph(m), rate(r), sigma(sg) {}
+    int count(int n) const {
+        int c = 1;
+        for (int k = 0; k < nd[n].nChild; ++k) c += count(nd[n].child[k]);
+        return c;
+    }
+    void mutate_params(MutNode &x) {
+        if (x.shape == 1) { // Standard2D.mutate, limitWH (simple_module.py:55-85)
+            if (rng.uniform() < morph) x.width = rng.gauss(x.width, sigma);
+            if (rng.uniform() < morph) x.height = rng.gauss(x.height, sigma);
+            if (rng.uniform() < morph) x.angle = rng.gauss(x.angle, sigma * PI);
+            x.height = std::min(std::max(x.height, P.box_min_height), P.box_max_height);
+            x.width = std::min(std::max(x.width, P.box_min_width), P.box_max_width);
+            x.angle = std::min(std::max(x.angle, P.box_min_angle), P.box_max_angle);
+        } else {            // Circular2D.mutate, limitWH (circular_module.py:55-80)
+            if (rng.uniform() < morph) x.radius = rng.gauss(x.radius, sigma);
+            if (rng.uniform() < morph) x.angle = rng.gauss(x.angle, sigma * PI);
+            x.radius = std::min(std::max(x.radius, P.circle_min_radius), P.circle_max_radius);
+            x.angle = std::min(std::max(x.angle, P.circle_min_angle), P.circle_max_angle);
+        }
+        // Controller.mutate: value += gauss(value, sigma) (m_controller.py:50-58), then minMax(module.angle)
+        if (rng.uniform() < rate) x.amp += rng.gauss(x.amp, sigma);
+        if (rng.uniform() < rate) x.phase += rng.gauss(x.phase, sigma);
+        if (rng.uniform() < rate) x.freq += rng.gauss(x.freq, sigma * 0.1);
+        if (rng.uniform() < rate) x.offset += rng.gauss(x.offset, sigma);
+        x.amp = std::min(std::max(x.amp, 0.0), P.ctl_max_amp);
+        x.phase = std::min(std::max(x.phase, -P.ctl_max_phase), P.ctl_max_phase);
+        x.freq = std::min(std::max(x.freq, -P.ctl_max_freq), P.ctl_max_freq);
+        if (x.offset > x.angle / 2) x.offset = x.angle / 2;
+        else if (x.offset < -x.angle / 2) x.offset = -x.angle / 2;
+    }
+    void mutate_node(int n, int depth) {
+        nModules = count(0);
+        // for mod in node.children: (a list iterator: the index advances whatever happens to the list)
+        for (int i = 0; i < nd[n].nChild; ++i) {
+            const int mod = nd[n].child[i];
+            if (rng.uniform() < morph / 2.0 / (double)nModules) {
+                if (depth != 0) {
+                    nd[n].freeSite[nd[mod].site] = true;                 // availableConnections.append(...)
+                    for (int k = i; k + 1 < nd[n].nChild; ++k) nd[n].child[k] = nd[n].child[k + 1];
+                    nd[n].nChild -= 1;                                   // children.remove(mod): the next sibling slides into slot i
+                    nModules = count(0);
+                }
+            } else {
+                mutate_node(mod, depth + 1);
+            }
+        }
+        // for con in node.availableConnections: (the same iterator semantics over the free sites, in the order left, right, top)
+        if (nd[n].shape == 1) {
+            int freeList[3], nFree = 0;
+            for (int sidx = 0; sidx < 3; ++sidx)
+                if (nd[n].freeSite[sidx]) freeList[nFree++] = sidx;
+            for (int k = 0; k < nFree; ++k) {
+                nModules = count(0);
+                if (nModules < P.max_modules && depth < P.max_depth && rng.uniform() < morph / (double)nModules) {
+                    const int ref = rng.randint(P.n_box + P.n_circle);
+                    if (nNodes >= 2 * MAXN || nd[n].nChild >= 3) continue;
+                    MutNode &c = nd[nNodes];
+                    c.shape = ref < P.n_box ? 1 : 2;                     // copy.deepcopy(self.moduleList[ref]): the prototypes keep their defaults
+                    c.width = c.shape == 1 ? P.proto_box_width : 0.0; c.height = c.shape == 1 ? P.proto_box_height : 0.0;
+                    c.radius = c.shape == 1 ? 0.0 : P.proto_circle_radius;
+                    c.angle = P.proto_angle; c.torque = P.proto_torque;
+                    c.amp = rng.uniform(0.0, P.ctl_max_amp);             // Controller()
+                    c.phase = rng.uniform(-P.ctl_max_phase, P.ctl_max_phase);
+                    c.freq = rng.uniform(-P.ctl_max_freq, P.ctl_max_freq);
+                    c.offset = rng.uniform(-P.ctl_max_offset, P.ctl_max_offset);
+                    c.site = freeList[k]; c.nChild = 0;
+                    for (int q = 0; q < 3; ++q) c.freeSite[q] = c.shape == 1;
+                    nd[n].child[nd[n].nChild++] = nNodes++;
+                    nd[n].freeSite[freeList[k]] = false;
+                    for (int q = k; q + 1 < nFree; ++q) freeList[q] = freeList[q + 1];   // availableConnections.remove(con) ...
+                    nFree -= 1;                                                          // ... and the iterator moves on past the next one
+                }
+            }
+        }
+        mutate_params(nd[n]);
+    }
+};
+
+} // namespace rem2d_host
+
+extern "C" int rem2d_mutate_trees(const rem2d_tree_population *P, double morph_rate, double rate, double sigma, uint64_t seed,
+                                  int32_t n_threads) {
+    using namespace rem2d_host;
+    if (!P || !P->node_count || !P->parent || !P->site || !P->shape || !P->width || !P->height || !P->radius || !P->angle ||
+        !P->torque || !P->ctl_amp || !P->ctl_phase || !P->ctl_freq || !P->ctl_offset)
+        return fail(REM2D_E_INVALID, "NULL argument");
+    const int n = P->n, M = P->max_nodes;
+    if (M <= 0 || M > MAXN || P->max_modules > M || P->max_modules <= 0) return fail(REM2D_E_INVALID, "max_nodes must be 1..64 and >= max_modules");
+    if (P->n_box < 0 || P->n_circle < 0 || P->n_box + P->n_circle <= 0) return fail(REM2D_E_INVALID, "no module prototypes");
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads > n) n_threads = n > 0 ? n : 1;
+    std::vector<int> status((size_t)(n_threads > 0 ? n_threads : 1), 0);
+    auto work = [&](int tid) {
+        const int per = (n + n_threads - 1) / n_threads;
+        const int e0 = tid * per, e1 = e0 + per < n ? e0 + per : n;
+        std::vector<TreeMutator> holder;
+        for (int e = e0; e < e1; ++e) {
+            holder.clear();
+            holder.emplace_back(*P, seed, (uint64_t)e, morph_rate, rate, sigma);
+            TreeMutator &T = holder[0];
+            const size_t o = (size_t)e * M;
+            const int cnt = P->node_count[e];
+            if (cnt <= 0 || cnt > M) { status[tid] = 1; continue; }
+            for (int i = 0; i < cnt; ++i) {     // the node table (Tree.getNodes() order) -> child lists in that order
+                MutNode &x = T.nd[i];
+                x.shape = P->shape[o + i]; x.site = P->site[o + i]; x.nChild = 0;
+                x.width = P->width[o + i]; x.height = P->height[o + i]; x.radius = P->radius[o + i]; x.angle = P->angle[o + i];
+                x.torque = P->torque[o + i]; x.amp = P->ctl_amp[o + i]; x.phase = P->ctl_phase[o + i]; x.freq = P->ctl_freq[o + i];
+                x.offset = P->ctl_offset[o + i];
+                for (int q = 0; q < 3; ++q) x.freeSite[q] = x.shape == 1;
+                if (i > 0) {
+                    const int p = P->parent[o + i];
+                    if (p < 0 || p >= i || x.site < 0 || x.site > 2 || T.nd[p].nChild >= 3) { status[tid] = 1; break; }
+                    T.nd[p].child[T.nd[p].nChild++] = i;
+                    T.nd[p].freeSite[x.site] = false;
+                }
+            }
+            if (status[tid]) continue;
+            T.nNodes = cnt;
+            T.mutate_node(0, 0);
+            // reassignIndices: back into Tree.getNodes() order
+            int stackN[2 * MAXN], stackP[2 * MAXN], top = 0, outN = 0;
+            stackN[top] = 0; stackP[top++] = -1;
+            while (top > 0) {
+                const int cur = stackN[--top], par = stackP[top];
+                if (outN >= M) { status[tid] = 1; break; }
+                const MutNode &x = T.nd[cur];
+                const int me = outN++;
+                P->parent[o + me] = par; P->site[o + me] = cur == 0 ? -1 : x.site; P->shape[o + me] = x.shape;
+                P->width[o + me] = x.width; P->height[o + me] = x.height; P->radius[o + me] = x.radius; P->angle[o + me] = x.angle;
+                P->torque[o + me] = x.torque; P->ctl_amp[o + me] = x.amp; P->ctl_phase[o + me] = x.phase;
+                P->ctl_freq[o + me] = x.freq; P->ctl_offset[o + me] = x.offset;
+                for (int k = x.nChild - 1; k >= 0; --k) { stackN[top] = x.child[k]; stackP[top++] = me; } // (first child on top)
+            }
+            for (int i = outN; i < M; ++i) {     // padding
+                P->parent[o + i] = -1; P->site[o + i] = -1; P->shape[o + i] = 0;
+                P->width[o + i] = P->height[o + i] = P->radius[o + i] = P->angle[o + i] = P->torque[o + i] = 0.0;
+                P->ctl_amp[o + i] = P->ctl_phase[o + i] = P->ctl_freq[o + i] = P->ctl_offset[o + i] = 0.0;
+            }
+            P->node_count[e] = outN;
+        }
+    };
+    if (n_threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+        for (auto &t : th) t.join();
+    }
+    for (int st : status)
+        if (st) return fail(REM2D_E_INVALID, "mutate_trees: a node table is not a tree in Tree.getNodes() order (or outgrew max_nodes)");
+    return REM2D_OK;
+}
+
 #endif

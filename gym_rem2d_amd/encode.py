@@ -248,13 +248,14 @@ def tree_batch_arrays(trees, module_lists=None, max_nodes=None):
     return a
 
 
-def compile_tree_arrays(arrays, lanes, n_threads=0):
-    """rem2d_compile_trees on node tables -> Morphology with `lanes` lanes per creature."""
+def compile_tree_arrays(arrays, lanes, n_threads=0, count_only=False):
+    """rem2d_compile_trees on node tables -> Morphology with `lanes` lanes per creature (count_only: the body counts, int32 [n],
+    nothing else computed -- the static cost key of evaluate.shard_balanced)."""
     import ctypes as C
     from . import _lib
     from .compiler import TERRAIN_HEIGHT
     n, M = arrays["index"].shape
-    m = Morphology(n, lanes)
+    m = Morphology(0 if count_only else n, lanes)
     B = _lib.TreeBatch()
     B.n, B.max_nodes = int(n), int(M)
     keep = []
@@ -265,9 +266,11 @@ def compile_tree_arrays(arrays, lanes, n_threads=0):
     out = _lib.Morph()
     for k in m.arrays:
         setattr(out, k, m.arrays[k].ctypes.data_as(C.c_void_p))
-    _lib.check(_lib.lib().rem2d_compile_trees(C.byref(B), float(TERRAIN_HEIGHT), int(lanes), C.byref(out),
-                                              m.n_bodies.ctypes.data_as(C.c_void_p), int(n_threads)))
-    return m
+    nb = np.zeros(n, dtype=np.int32) if count_only else m.n_bodies
+    _lib.check(_lib.lib().rem2d_compile_trees(C.byref(B), float(TERRAIN_HEIGHT), 64 if count_only else int(lanes),
+                                              None if count_only else C.byref(out), nb.ctypes.data_as(C.c_void_p),
+                                              int(n_threads)))
+    return nb if count_only else m
 
 
 def encode_trees_native(individuals, tree_depth=None, n_threads=0):
@@ -322,15 +325,15 @@ def network_genome_arrays(genomes):
     return a
 
 
-def compile_network_arrays(arrays, tree_depth, max_modules, lanes, n_threads=0):
-    """rem2d_compile_network on genome arrays -> Morphology with `lanes` lanes per creature."""
+def compile_network_arrays(arrays, tree_depth, max_modules, lanes, n_threads=0, count_only=False):
+    """rem2d_compile_network on genome arrays -> Morphology with `lanes` lanes per creature (count_only: the body counts only)."""
     import ctypes as C
     from . import _lib
     from .compiler import TERRAIN_HEIGHT
     from .controller import Controller
     from .modules import Circular2D, Standard2D
     n, T = arrays["mod_shape"].shape
-    m = Morphology(n, lanes)
+    m = Morphology(0 if count_only else n, lanes)
     G = _lib.NetworkGenomes()
     G.n, G.n_types, G.n_hidden, G.max_modules = int(n), int(T), int(arrays["a1"].shape[1]), int(max_modules)
     keep = []
@@ -349,9 +352,11 @@ def compile_network_arrays(arrays, tree_depth, max_modules, lanes, n_threads=0):
     out = _lib.Morph()
     for k in m.arrays:
         setattr(out, k, m.arrays[k].ctypes.data_as(C.c_void_p))
-    _lib.check(_lib.lib().rem2d_compile_network(C.byref(G), int(tree_depth), float(TERRAIN_HEIGHT), int(lanes), C.byref(out),
-                                                m.n_bodies.ctypes.data_as(C.c_void_p), int(n_threads)))
-    return m
+    nb = np.zeros(n, dtype=np.int32) if count_only else m.n_bodies
+    _lib.check(_lib.lib().rem2d_compile_network(C.byref(G), int(tree_depth), float(TERRAIN_HEIGHT),
+                                                64 if count_only else int(lanes), None if count_only else C.byref(out),
+                                                nb.ctypes.data_as(C.c_void_p), int(n_threads)))
+    return nb if count_only else m
 
 
 def encode_network_native(individuals, tree_depth=None, n_threads=0):

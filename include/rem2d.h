@@ -30,7 +30,7 @@ extern "C" {
 #define REM2D_ABI_VERSION 9 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
                                7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar;
-                               9: + rem2d_build_id; worlds of tile shapes 0 and 2 are refused in one launch */
+                               9: + rem2d_build_id, rem2d_mutate_trees, count-only compilers (out == NULL); worlds of tile shapes 0 and 2 are refused in one launch */
 
 enum {
     REM2D_OK = 0,
@@ -329,6 +329,31 @@ typedef struct {
 } rem2d_tree_batch;
 int rem2d_compile_trees(const rem2d_tree_batch *trees, double terrain_height, int32_t lanes, const rem2d_morph *out,
                         int32_t *n_bodies, int32_t n_threads);
+
+/* DirectEncoding.mutate (Encodings/Direct_Encoding.py:82-139: removal of subtrees, growth on free connection sites, then
+ * module.mutate / controller.mutate of every visited node -- simple_module.py:70-85, circular_module.py:67-80,
+ * m_controller.py:50-58) for a whole population of direct-encoding genomes held as node tables, IN PLACE: what
+ * REM2D_main.py:280-298 does to every offspring of every generation, one python object at a time.  HOST pointers, [n][max_nodes]
+ * in Tree.getNodes() order (a node's subtree is the run of columns behind it; parent = the parent's column, -1 for the root);
+ * the same tables rem2d_compile_trees reads (its `index` is the column).  The reference's algorithm with its list-iterator
+ * semantics and recounts; its own random stream: one generator per individual seeded from (seed, individual), so the result
+ * does not depend on n_threads. */
+typedef struct {
+    int32_t n, max_nodes;                      /* individuals, columns of the tables (<= 64) */
+    int32_t *node_count;                       /* [n] */
+    int32_t *parent, *site, *shape;            /* [n][max_nodes]: parent column, 0 left / 1 right / 2 top (-1 root), 1 box / 2 circle / 0 padding */
+    double *width, *height, *radius, *angle, *torque;
+    double *ctl_amp, *ctl_phase, *ctl_freq, *ctl_offset;
+    int32_t max_modules, max_depth;            /* DirectEncoding.maxModules / maxDepth (20 / 8) */
+    int32_t n_box, n_circle;                   /* the module list's prototypes a new node copies (REM2D_main.py:69-77: 4 + 4) */
+    double proto_box_width, proto_box_height, proto_circle_radius, proto_angle, proto_torque; /* their (never mutated) defaults */
+    /* class constants, handed over like rem2d_network_genomes' */
+    double box_min_width, box_max_width, box_min_height, box_max_height, box_min_angle, box_max_angle;
+    double circle_min_radius, circle_max_radius, circle_min_angle, circle_max_angle;
+    double ctl_max_amp, ctl_max_phase, ctl_max_offset, ctl_max_freq;
+} rem2d_tree_population;
+int rem2d_mutate_trees(const rem2d_tree_population *pop, double morph_rate, double rate, double sigma, uint64_t seed,
+                       int32_t n_threads);
 
 /* The network encoding end to end (Encodings/Network_Encoding.py:42-222: update / iterate / create / recursiveNodeGen --
  * one network query per free connection site decides whether a child exists, its module type, shape (setMorph,

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # entry points of include/rem2d.h without a twin, and why
 HOST_ONLY = {
     "rem2d_plan_tiles", "rem2d_plan_tiles_shape", "rem2d_compile_lsystem", "rem2d_compile_trees", "rem2d_compile_network",  # host code already
+    "rem2d_mutate_trees",
     "rem2d_tree_diversity",  # its CPU restatement is oracle.tree_distance_matrix (tests/test_diversity.py)
     "rem2d_selftest_scalar",  # its CPU restatement is rem2d_oracle_kat_scalar / rem2d_oracle_sincosf
 }
