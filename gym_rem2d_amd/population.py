@@ -161,8 +161,7 @@ class LSystemPopulation:
     # ------------------------------------------------------------------ variation
     def select(self, idx):
         """Clone the individuals `idx` (tools.selTournament + toolbox.clone, REM2D_main.py:283-285)."""
-        idx = np.asarray(idx, dtype=np.int64)
-        return LSystemPopulation({k: v[idx].copy() for k, v in self.a.items()}, self.tree_depth, self.max_modules)
+        return LSystemPopulation(_take(self.a, np.asarray(idx, dtype=np.int64)), self.tree_depth, self.max_modules)
 
     def _mutate_modules(self, morph_rate, rate, sigma, rng):
         mutate_module_arrays(self.a, morph_rate, rate, sigma, rng)

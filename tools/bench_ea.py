@@ -67,6 +67,12 @@ def main():
                           host_workers=args.workers or min(os.cpu_count() or 1, 64), generations=rows)))
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup's CPU quota (bench.host_cores)."""
+    import bench
+    return bench.host_cores()[0]
+
+
 def main_arrays(args):
     import numpy as np
     from gym_rem2d_amd.population import DirectPopulation, LSystemPopulation, NetworkPopulation, tournament
@@ -110,8 +116,7 @@ def main_arrays(args):
         rows.append(dict(generation=gen, select_clone_mutate_s=t_var, of_which_select_s=t_sel, encode_s=t_enc,
                          host_s=t_var + t_enc, upload_and_episode_s=t_gpu, steps=steps, best=float(fit.max())))
     print(json.dumps(dict(metric="wall seconds per EA generation", mode="arrays + native compiler", encoding=args.encoding,
-                          population=args.population, init_s=t_init, host_cores=os.cpu_count(),
-                          host_threads=len(os.sched_getaffinity(0)), generations=rows)))
+                          population=args.population, init_s=t_init, host_cores=_usable_cores(), generations=rows)))
 
 
 if __name__ == "__main__":
