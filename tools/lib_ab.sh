@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of library builds on the driver's own command:  bash tools/r04_lib_ab.sh <tag> <pairs> <name1> [name2 ...]
+# A/B of library builds on the driver's own command:  bash tools/lib_ab.sh <tag> <pairs> <name1> [name2 ...]
 # names: "base" = gym_rem2d_amd/librem2d.so, anything else = build/ab/librem2d_<name>.so (tools/build_variant.sh).
 # Extra bench arguments through BENCH_ARGS, extra environment per variant as name:VAR=VALUE.
 set -u
 TAG=$1; N=$2; shift 2
-O=gpurun_out/r04_ab_$TAG; mkdir -p $O
+O=gpurun_out/ab_$TAG; mkdir -p $O
 ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --no-secondary --min-time 1}
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --min-time 0.3 > /dev/null 2>&1
 for i in $(seq 1 $N); do

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything measured for a round, on the GPU box: gpurun --timeout 3000 -- 'bash tools/round_gpu_run.sh r04_final'
+# Everything measured for a round, on the GPU box: gpurun --timeout 3000 -- 'bash tools/round_gpu_run.sh r05_final'
 # (each command under its own timeout so that a hang cannot eat the GPU budget).  The driver's command runs FIRST, as the
 # first GPU process of the lease (cold), then again (warm).
 set -u
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20_cold.json 2> $O/bench_cold.err
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_20.json 2>/dev/null
@@ -29,3 +29,5 @@ bash tools/profile_round.sh ${TAG%_final} > $O/profile.log 2>&1; tail -3 $O/prof
 timeout 600 python tools/soak_parity.py --n 6000 --steps 300 > $O/soak_parity.txt 2>&1; tail -4 $O/soak_parity.txt
 timeout 600 python tools/fuzz_launch_shapes.py --rounds 40 --seed 1 > $O/fuzz_launch_shapes.txt 2>&1; tail -1 $O/fuzz_launch_shapes.txt
 timeout 600 python tools/fuzz_episode.py --rounds 30 --seed 1 > $O/fuzz_episode.txt 2>&1; tail -1 $O/fuzz_episode.txt
+timeout 900 python3 tools/fma_tolerance.py --n 1024 --steps 150 > $O/fma_tolerance.txt 2>&1; tail -6 $O/fma_tolerance.txt
+bash tools/r05_bench_ea.sh 1048576 > $O/bench_ea.txt 2>&1; cp gpurun_out/r05_bench_ea/bench_ea_*.json $O/ 2>/dev/null; cat $O/bench_ea.txt

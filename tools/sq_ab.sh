@@ -1,10 +1,10 @@
 #!/bin/bash
 # SQ counters (VALU wave-instructions, active lanes) of the step kernels for library builds x environment overrides:
-#   bash tools/r04_sq_ab.sh <tag> <spec> [spec ...]     spec = base | <variant>[+label][:VAR=VALUE[,VAR=VALUE]]
+#   bash tools/sq_ab.sh <tag> <spec> [spec ...]     spec = base | <variant>[+label][:VAR=VALUE[,VAR=VALUE]]
 # One rocprofv3 --pmc pass per spec (counters only: --kernel-trace, no other trace domain), reduced by collect_profiles.py sq.
 set -u
 TAG=$1; shift
-O=$GRAFT_REPO_ROOT/gpurun_out/r04_sq_$TAG; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/sq_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ARGS=${BENCH_ARGS:---steps 10 --warmup 2 --settle 80 --no-cpu-baseline --no-secondary --min-time 0}
 python3 bench.py $ARGS > /dev/null 2>&1     # (builds and caches the genomes: no fork under the profiler)
