@@ -494,9 +494,11 @@ def main():
     # collective): the line shows how even the cut is
     my_cost = int(sum(int(m.n_bodies.sum()) for m in morphs)) if not single else 0
     shard_cost = [my_cost]
-    if world > 1:
-        shard_cost = [None] * world
-        dist.all_gather_object(shard_cost, my_cost)
+    if world > 1:   # (the same kind of collective as the fitness all-gather, on the same device: nothing new for RCCL to do)
+        mine = torch.tensor([my_cost], dtype=torch.int64, device=cdev)
+        every = torch.empty(world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(every, mine)
+        shard_cost = [int(v) for v in every.cpu().tolist()]
     if generation:
         args.settle = args.warmup = 0
     run(args.settle)
