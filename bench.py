@@ -62,7 +62,7 @@ def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     gfx950; newest round first)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r01_f_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r01_f_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -78,7 +78,7 @@ def pmc_traffic(kernel_name):
 
 def pmc_traffic_all():
     """HBM bytes of every kernel of one env-step sequence (per launch of one step group), from the same PMC passes."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -93,10 +93,10 @@ def pmc_traffic_all():
 
 def valu_issue(n_groups):
     """VALU wave-instructions per env-step of the default population from the committed SQ-counter pass
-    (profiles/r04_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
+    (profiles/r05_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
     measured issue peak (tools/ubench_latency.hip -> profiles/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s
     with 8 dependent chains per SIMD).  Only when this run uses the step-group count the counters were collected with."""
-    for name in ("r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json"):
+    for name in ("r05_sq_counters.json", "r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
