@@ -25,13 +25,16 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--max-modules", type=int, default=15)
     ap.add_argument("--chunk", type=int, default=8192, help="individuals per oracle call (bounds host memory)")
-    ap.add_argument("--encoding", choices=["lsystem", "network"], default="lsystem",
-                    help="network: config 4's generator (one network-encoded creature per seed) on the hardcore track")
+    ap.add_argument("--encoding", choices=["lsystem", "network", "direct", "network_arrays"], default="lsystem",
+                    help="network: config 4's generator (one network-encoded creature per seed) on the hardcore track; direct / "
+                         "network_arrays: round 5's array populations (DirectPopulation / NetworkPopulation, `--mutations` rounds "
+                         "of mutate(0.2, 0.2, 0.2) after construction) on the default terrain")
+    ap.add_argument("--mutations", type=int, default=3)
     args = ap.parse_args()
     from gym_rem2d_amd import _lib, make_terrain
     from gym_rem2d_amd.env import BatchedModular2D
     from gym_rem2d_amd.evaluate import run_episode
-    from gym_rem2d_amd.population import LSystemPopulation
+    from gym_rem2d_amd.population import DirectPopulation, LSystemPopulation, NetworkPopulation
     from oracle import oracle as O
     O.build()
     rng = np.random.default_rng(args.seed)
@@ -43,7 +46,15 @@ def main():
                    synthetic.cppn_batches_native(range(args.seed * 10 ** 6, args.seed * 10 ** 6 + args.n), n_proc=4)]
         select = None
     else:
-        pop = LSystemPopulation.random(args.n, rng, max_modules=args.max_modules)
+        if args.encoding == "direct":
+            pop = DirectPopulation.random(args.n, rng)
+        elif args.encoding == "network_arrays":
+            pop = NetworkPopulation.random(args.n, rng)
+        else:
+            pop = LSystemPopulation.random(args.n, rng, max_modules=args.max_modules)
+        if args.encoding != "lsystem":
+            for _ in range(args.mutations):
+                pop.mutate(0.2, 0.2, 0.2, rng)
         batches = pop.compile(0)
     env = BatchedModular2D(hardcore=hard, flags=_lib.FLAG_CONTINUOUS | _lib.FLAG_SKIP_FROZEN)
     env._upload(batches, args.n)
