@@ -168,3 +168,79 @@ def test_array_generation_on_gpu_equals_generation_with_the_oracle(encoding, ora
     assert np.array_equal(f1, f2) and h1 == h2 and len(set(f1.tolist())) > 10
     for k in p1.a:
         assert np.array_equal(p1.a[k], p2.a[k]), k
+
+
+def test_count_only_compilers_and_error_paths(built):
+    """out == NULL turns the three native compilers into body counters (the cost key of evaluate.shard_balanced); a node table that
+    is not a tree in Tree.getNodes() order is refused by rem2d_mutate_trees with an error code, not a crash."""
+    import ctypes as C
+    from gym_rem2d_amd import _lib
+    rng = np.random.default_rng(3)
+    ls = LSystemPopulation.random(300, rng, max_modules=15)
+    order = np.argsort(np.concatenate([np.asarray(i) for _, i in ls.compile(2)]))
+    assert np.array_equal(ls.body_counts(2), np.concatenate([m.n_bodies for m, _ in ls.compile(2)])[order])
+    pop = DirectPopulation.random(50, rng)
+    good = {k: v.copy() for k, v in pop.a.items()}
+    pop.a["parent"][7, 1] = 5                       # a parent BEHIND its child: not pre-order
+    with pytest.raises(_lib.Rem2dError, match="Tree.getNodes"):
+        pop.mutate(0.1, 0.1, 0.1, rng)
+    pop.a = {k: v.copy() for k, v in good.items()}
+    pop.a["node_count"][3] = 0
+    with pytest.raises(_lib.Rem2dError):
+        pop.mutate(0.1, 0.1, 0.1, rng)
+    assert _lib.lib().rem2d_mutate_trees(None, 0.1, 0.1, 0.1, 1, 1) == -1
+    # morph_rate 0: no structural change, only (some) parameters move; rate 0 as well: nothing moves at all
+    pop.a = {k: v.copy() for k, v in good.items()}
+    pop.mutate(0.0, 0.0, 0.1, rng)
+    for k in ("node_count", "parent", "site", "shape", "ctl_amp", "ctl_phase", "ctl_freq"):
+        assert np.array_equal(pop.a[k], good[k]), k
+    live = good["shape"] > 0                        # (limitWH / minMax of the visited nodes may still clamp: width 0.2 -> 0.5)
+    assert (pop.a["width"][live & (good["shape"] == 1)] >= 0.5).all()
+
+
+def test_shard_balanced_edge_cases():
+    from gym_rem2d_amd.evaluate import shard_balanced, shard_costs
+    assert shard_balanced(np.zeros(0), 4).shape == (4, 0)
+    idx = shard_balanced(np.array([5, 9, 2]), 8)                       # more ranks than individuals
+    assert idx.shape == (8, 1) and sorted(idx[idx >= 0].tolist()) == [0, 1, 2] and (idx >= 0).sum() == 3
+    assert shard_costs(np.array([5, 9, 2]), idx).sum() == 16
+    assert np.array_equal(shard_balanced(np.array([1, 8, 3, 8]), 1), [[1, 3, 2, 0]])   # ties keep population order
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    g.build()
+    from gym_rem2d_amd.population import DirectPopulation, NetworkPopulation, run_generations, sharded_evaluator
+    for name, make in (("direct", lambda r: DirectPopulation.random(203, r)), ("network", lambda r: NetworkPopulation.random(101, r))):
+        rng = np.random.default_rng(12)
+        ev = sharded_evaluator(lambda block: block.body_counts(1).astype(np.float64) * 1.5, n_threads=1)
+        pop, fit, hist = run_generations(make(rng), 2, ev, rng, 0.2, 0.2, 0.2)
+        np.save(os.path.join(out_dir, "%s_fit%d.npy" % (name, rank)), fit)
+        np.save(os.path.join(out_dir, "%s_cost%d.npy" % (name, rank)), ev.last_shard_cost)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_generations_of_the_direct_and_network_populations_gloo(tmp_path, built):
+    """World size 2 over gloo: replicated variation, cost-balanced shards, one fitness all-gather per generation -- every rank
+    ends with the single-process fitness, and the ranks' predicted costs are within 5 % of each other."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for name, make in (("direct", lambda r: DirectPopulation.random(203, r)), ("network", lambda r: NetworkPopulation.random(101, r))):
+        rng = np.random.default_rng(12)
+        pop, fit, hist = run_generations(make(rng), 2, lambda p: p.body_counts(1).astype(np.float64) * 1.5, rng, 0.2, 0.2, 0.2)
+        for r in range(2):
+            assert np.array_equal(np.load(os.path.join(str(tmp_path), "%s_fit%d.npy" % (name, r))), fit), name
+            cost = np.load(os.path.join(str(tmp_path), "%s_cost%d.npy" % (name, r)))
+            assert cost.sum() == pop.body_counts(1).sum() and abs(cost[0] - cost[1]) <= 0.05 * cost.mean(), (name, cost)
