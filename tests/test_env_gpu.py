@@ -291,6 +291,10 @@ def test_bench_json_contract(need_gpu):
     assert abs(d["ms_per_step"] * d["steps"] - float(np.median(cfg["blocks_ms"]))) < 1e-2
     assert abs(d["value"] - cfg["creatures_total"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
     assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    # round 5: the line names the build it measured and the job's shape
+    from gym_rem2d_amd import _lib
+    assert d["build_id"] == _lib.source_id() and d["world_size"] == 1 and d["backend"] is None
+    assert cfg["shard_cost_bodies"] and len(cfg["shard_cost_bodies"]) == 1 and cfg["shard_cost_bodies"][0] > 1024
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
@@ -313,6 +317,9 @@ def test_bench_gpus_flag_starts_the_ranks_itself(need_gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["metric"] == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]   # the same string at every N
     assert d["config"]["envs_per_gpu"] == 512 and d["config"]["creatures_total"] == 1024 and d["config"]["solver_errors"] == 0
+    # the line says how many ranks took part in the collective, over what, and how even the shards were
+    assert d["world_size"] == 2 and d["backend"] in ("gloo", "nccl") and len(d["config"]["shard_cost_bodies"]) == 2
+    assert min(d["config"]["shard_cost_bodies"]) > 512
     # strong scaling: the same population split over the ranks
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--envs", "512", "--settle", "5", "--no-cpu-baseline", "--scaling", "strong", "--min-time", "0"],
