@@ -33,6 +33,18 @@ template <int WORK> __global__ void __launch_bounds__(128) pingpong(float *out, 
     out[blockIdx.x * 128 + threadIdx.x] = a;
     if ((threadIdx.x & 63) == 0) stamps[2 * blockIdx.x + wave] = t1 - t0;
 }
+// two wavefronts that BOTH run `WORK` instructions per turn and meet at a workgroup barrier after each: what s_barrier itself costs
+template <int WORK> __global__ void __launch_bounds__(128) barrier_pair(float *out, unsigned long long *stamps, int turns) {
+    float a = 1.0f + threadIdx.x * 1e-7f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < turns; ++t) {
+        a = chain<WORK>(a, 0.999f, 1e-9f);
+        __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 128 + threadIdx.x] = a;
+    if ((threadIdx.x & 63) == 0) stamps[2 * blockIdx.x + (threadIdx.x >> 6)] = t1 - t0;
+}
 // the same number of turns by ONE wavefront
 template <int WORK> __global__ void __launch_bounds__(64) serial(float *out, unsigned long long *stamps, int turns) {
     float a = 1.0f + threadIdx.x * 1e-7f;
@@ -60,9 +72,16 @@ template <int WORK> int run(float *out, unsigned long long *st, int ncu) {
         std::vector<double> se;
         for (int b = 0; b < 2 * blocks; ++b) se.push_back((double)g[b] / turns);
         std::sort(se.begin(), se.end());
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(barrier_pair<WORK>, dim3(blocks), dim3(128), 0, 0, out, st, turns);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), st, 2 * blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> bp;
+        for (int b = 0; b < blocks; ++b) bp.push_back((double)std::max(h[2 * b], h[2 * b + 1]) / turns);
+        std::sort(bp.begin(), bp.end());
         printf("%3d dependent v_fma per turn, %d block(s) per CU: one wavefront %.0f ticks per turn; two wavefronts alternating through LDS %.0f "
-               "(median; p90 %.0f) -> the hand-off costs %.0f ticks\n", WORK, per_cu, se[se.size() / 2], pp[pp.size() / 2], pp[pp.size() * 9 / 10],
-               pp[pp.size() / 2] - se[se.size() / 2]);
+               "(median; p90 %.0f) -> the hand-off costs %.0f ticks; two wavefronts side by side + s_barrier per turn %.0f -> the barrier costs %.0f\n",
+               WORK, per_cu, se[se.size() / 2], pp[pp.size() / 2], pp[pp.size() * 9 / 10], pp[pp.size() / 2] - se[se.size() / 2],
+               bp[bp.size() / 2], bp[bp.size() / 2] - se[se.size() / 2]);
     }
     return 0;
 }
