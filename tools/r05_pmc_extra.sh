@@ -6,7 +6,11 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ARGS="--steps 10 --warmup 2 --settle 80 --no-cpu-baseline --no-secondary --min-time 0"
 python3 bench.py $ARGS > /dev/null 2>&1
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"; do
+# PMC_GROUPS="A B C;D E": other counter groups (';' between passes), e.g. the instruction-cache pass
+#   PMC_GROUPS="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE;SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"
+DEFAULT_GROUPS="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES;SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
+IFS=';' read -ra GROUPS_ <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
+for grp in "${GROUPS_[@]}"; do
   i=$((i+1))
   timeout 420 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/raw$i -- python3 bench.py $ARGS > /dev/null 2> $O/err$i.txt
   f=$(find $O/raw$i -name "*counter_collection.csv" | head -1)
