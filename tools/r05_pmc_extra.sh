@@ -21,7 +21,7 @@ rows = list(csv.DictReader(open(f)))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r.get("Kernel_Name", "")
-    if "rem2d_velpost" in k or "rem2d_pre" in k or "rem2d_toi_heavy" in k:
+    if "rem2d_velpost" in k or "rem2d_pre" in k or "rem2d_toi_heavy" in k or "rem2d_step_tile" in k:
         acc[k.split("(")[0]][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for k, cs in acc.items():
     out = []
