@@ -86,7 +86,7 @@ def pmc_traffic_all():
         except Exception:  # noqa: BLE001
             continue
         ks = {k.split("<")[0].split("(")[0]: float(v["hbm_bytes_per_launch"]) for k, v in d["kernels"].items()
-              if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi"))}
+              if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi", "rem2d_step_train"))}
         return {"bytes_per_launch_sequence": sum(ks.values()), "by_kernel": ks, "source": os.path.relpath(path, ROOT)}
     return None
 
@@ -107,7 +107,7 @@ def valu_issue(n_groups):
         if groups != n_groups:
             return None
         per_group = sum(v["SQ_INSTS_VALU"] for k, v in d["kernels"].items()
-                        if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi")))
+                        if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi", "rem2d_step_train")))
         return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
                 "source": "profiles/%s (per launch of one of the %d step groups of this command), "
                           "profiles/r02_b_ubench_valu_latency.txt" % (name, n_groups)}
@@ -560,7 +560,9 @@ def main():
         # (the library's answer: velocity tiles and position iterations of a 64-lane block in ONE launch -- then that launch,
         # rem2d_velpost_kernel, is the dominant kernel and what the HIP events above timed)
         _, fused_velpost = env.launch_info()
-        if fused_velpost:
+        if fused_velpost == 2:     # the step train: all steps of a call and all phases of a step in one launch
+            kname = "rem2d_step_train_kernel"
+        elif fused_velpost:
             kname = "rem2d_velpost_kernel"
     bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
     flops_per_step = float(sum(valu_flops_per_env_step(m.n_bodies).sum() for m in morphs))
@@ -640,7 +642,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload_desc, "creatures_total": total, "envs_per_gpu": n_envs,
-                       "pipeline": ("tile (pre / velpost = vel4 + post + toi_scan / toi_heavy)" if fused_velpost else
+                       "pipeline": ("step train (one launch per call: a workgroup per (step, 64-lane block) runs pre + vel4 + post + the TOI solve "
+                                    "of its own bodies, block-steps handed over through flags inside an XCD)" if fused_velpost == 2 else
+                                    "tile (pre / velpost = vel4 + post + toi_scan / toi_heavy)" if fused_velpost else
                                     {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels"}[pipeline]),
                        "kernel_launches_per_env_step_per_group": ((4 if not args.discrete else 3) - (1 if fused_velpost else 0))
                        if pipeline == 3 else None,

@@ -32,6 +32,7 @@ STEP_GRAPH = 1
 SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
+ERR_HANDOVER = 4   # (the step train's hand-over check, include/rem2d.h)
 
 # launch options of a world (include/rem2d.h REM2D_OPT_*, rem2d_world_set_option): no result depends on them
 OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug", "rebalance")
@@ -136,7 +137,11 @@ class Rem2dError(RuntimeError):
 # -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov) than it saves here;
 # without it the step kernel fits 238 VGPRs with no spills (+11..14 % env-steps/s).  -ffp-contract=off keeps every binary32
 # operation separately rounded (what the bit-exact parity rests on).
-BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared"]
+# (-instcombine-max-copied-from-constant-users: a kernel reads its by-value `Batch` argument straight from the kernarg segment only
+# while LLVM's scan of the argument's users stays under this limit -- 300 by default, which rem2d_step_train_kernel's inlined
+# phases exceed: the whole 1.5 KB struct was copied to scratch and spilled from there; the other kernels compile the same either way)
+BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
+               "-mllvm", "-instcombine-max-copied-from-constant-users=4000"]
 WIDE_FLAGS = ["-DREM2D_WIDE=1"]
 FMA_FLAGS = ["-ffp-contract=fast"]   # (the later -ffp-contract wins over BUILD_FLAGS')
 
@@ -281,7 +286,7 @@ def lib(wide=False):
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 9:
+    if L.rem2d_abi_version() != 10:
         raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
     L.rem2d_build_id.restype = C.c_char_p
     # the library must have been built from the sources beside it (REM2D_LIB_PATH / REM2D_WIDE_LIB_PATH name an experiment's

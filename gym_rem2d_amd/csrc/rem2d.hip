@@ -132,6 +132,7 @@ struct rem2d_world {
     uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
     int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
     int64_t stepsQueued;          // env-steps queued so far (the cadence of REM2D_OPT_REBALANCE)
+    int *trainFlags; size_t trainCap; // rem2d_step_train_kernel's hand-over flags (device; grown on demand, as the first world of a launch)
     bool hostOrder;               // rem2d_world_set_order installed an order (REM2D_STATE_ORDERED = hostOrder || REBALANCE > 0)
 };
 // the kernels go through State::order while the host has installed an order OR the library re-makes one every N steps
@@ -183,9 +184,9 @@ static int default_tile_creatures(const TileShape &shp, int lanes) {
 //   DEBUG          diagnostic builds (-DREM2D_V4_PROBES) only: Vel4Args::dbg
 //   REBALANCE      N > 0: every N env-steps the world's creature order is re-made on the device (rem2d_rebalance_kernel: the
 //                  creatures that used every position iteration first, a stable partition), 0 = off
-static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0, 0};
+static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 2, 5, 60, 75, 1, 0, 0};
 static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0};
-static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, WAVE, 1 << 30, 1 << 20};
+static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 2, 7, 1 << 20, 1 << 20, WAVE, 1 << 30, 1 << 20};
 
 static uint32_t __float_as_uint_host(float f) {
     uint32_t u;
@@ -579,6 +580,7 @@ extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (w->S.order) (void)hipFree(w->S.order);
     if (w->tilesDev) (void)hipFree(w->tilesDev);
     if (w->terrainBuf) (void)hipFree(w->terrainBuf);
+    if (w->trainFlags) (void)hipFree(w->trainFlags);
     delete w;
     return REM2D_OK;
 }
@@ -741,6 +743,7 @@ struct TilePlan {
     int launchShape;
     bool continuous;
     bool velpost; // one launch for the velocity iterations and post (rem2d_velpost_kernel)
+    bool train;   // ... and ONE launch for all steps of a call, pre and the TOI solve included (rem2d_step_train_kernel; REM2D_OPT_FUSE_VELPOST = 2)
     rem2d_world *w0;
     rem2d_world *ws[REM2D_MAX_BATCH]; // the group's worlds (REM2D_OPT_REBALANCE runs per world)
     int nw;
@@ -788,6 +791,10 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
     P.velpost = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] != 0 && P.launchShape == 3;
     for (int i = 0; i < n_worlds; ++i)
         P.velpost = P.velpost && ws[i]->S.tileCap > 0 && ws[i]->tileShape == 3; // (REM2D_FLAG_RETILE: tile slots and block slots go through the same creature order)
+    // the step train: where the one-launch form is possible, for worlds whose creature order does not change inside a launch
+    // (REM2D_FLAG_RETILE re-deals it in every step, grid-wide) and outside the fused kernel's diagnostics (REM2D_OPT_DEBUG)
+    P.train = P.velpost && ws[0]->opt[REM2D_OPT_FUSE_VELPOST] == 2 && ws[0]->opt[REM2D_OPT_DEBUG] == 0;
+    for (int i = 0; i < n_worlds; ++i) P.train = P.train && !(ws[i]->cfg.flags & REM2D_FLAG_RETILE);
     P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     P.A.nSteps = 1;
     P.A.dt = dt;
@@ -874,9 +881,65 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
         w0->evUsedStep += 1;
     }
 }
+// The step train (rem2d_step_train_kernel): the steps of a call in one launch -- or in one launch per stretch between two
+// re-orderings of the creature order (REM2D_OPT_REBALANCE), which run in front of the stretch they are due for.
+static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
+    rem2d_world *w0 = P.w0;
+    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.blocks;
+    if (w0->trainCap < need) {
+        if (w0->trainFlags) HIP_TRY(hipFree(w0->trainFlags)); // (blocks until earlier launches that use it are done)
+        w0->trainFlags = nullptr; w0->trainCap = 0;
+        HIP_TRY(hipMalloc(&w0->trainFlags, need * sizeof(int)));
+        w0->trainCap = need;
+    }
+    const unsigned nPad = (P.blocks + 7u) & ~7u;
+    int l = 0;
+    while (l < n_steps) {
+        int seg = n_steps - l;
+        if ((unsigned long long)nPad * (unsigned)seg > 0x7fffffffull) seg = (int)(0x7fffffffull / nPad);
+        for (int i = 0; i < P.nw; ++i) {
+            const int every = P.ws[i]->opt[REM2D_OPT_REBALANCE];
+            if (every > 0) {
+                const int to_next = every - (int)(P.ws[i]->stepsQueued % every);
+                seg = seg < to_next ? seg : to_next;
+            }
+        }
+        const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
+                               hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
+        for (int i = 0; i < P.nw; ++i) {
+            rem2d_world *w = P.ws[i];
+            const int every = w->opt[REM2D_OPT_REBALANCE];
+            if (every > 0 && w->stepsQueued > 0 && w->stepsQueued % every == 0 && (w->S.flags & REM2D_STATE_ORDERED)) {
+                int threads = WAVE;
+                while (threads < REBALANCE_MAX_THREADS && threads * 256 < w->cfg.n_envs) threads *= 2;
+                hipLaunchKernelGGL(rem2d_rebalance_kernel, dim3(1), dim3(threads), 0, st, w->S, P.A.posIters);
+            }
+            w->stepsQueued += seg;
+        }
+        HIP_TRY(hipMemsetAsync(w0->trainFlags, 0, need * sizeof(int), st));
+        P.A.nSteps = seg;
+        const dim3 grid(nPad * (unsigned)seg), block(WAVE);
+        if (w0->timing && w0->evUsed < (int)w0->evPool.size()) {
+            hipExtLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, w0->evPool[w0->evUsed].first, w0->evPool[w0->evUsed].second, 0,
+                                  P.B, P.A, P.V, w0->trainFlags, P.blocks);
+            w0->evUsed += 1;
+        } else {
+            hipLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, P.B, P.A, P.V, w0->trainFlags, P.blocks);
+        }
+        if (timedStep) {
+            (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
+            w0->evUsedStep += 1;
+        }
+        l += seg;
+    }
+    P.A.nSteps = 1;
+    HIP_TRY(hipGetLastError());
+    return REM2D_OK;
+}
 static int step_tiles(rem2d_world *const *ws, int n_worlds, int n_steps, float dt, int vel_iters, int pos_iters, hipStream_t st) {
     TilePlan P;
     tiles_plan(P, ws, n_worlds, dt, vel_iters, pos_iters);
+    if (P.train) return tiles_launch_train(P, st, n_steps);
     for (int l = 0; l < n_steps; ++l) tiles_launch_step(P, st);
     HIP_TRY(hipGetLastError());
     return REM2D_OK;
@@ -937,7 +1000,7 @@ extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds
     SHAPES_TRY(ws, n_worlds);
     tiles_plan(P, ws, n_worlds, 1.0f / 50.0f, 180, 60);
     if (tile_shape_out) *tile_shape_out = P.launchShape;
-    if (fused_velpost) *fused_velpost = P.velpost ? 1 : 0;
+    if (fused_velpost) *fused_velpost = P.train ? 2 : (P.velpost ? 1 : 0);
     return REM2D_OK;
 }
 
@@ -1054,9 +1117,14 @@ static int groups_enqueue(const rem2d_step_group *groups, int n_groups, int n_st
         // the host is still busy queueing another group's whole train (and the groups start together)
         std::vector<TilePlan> plans((size_t)n_groups);
         for (int g = 0; g < n_groups; ++g) tiles_plan(plans[g], groups[g].worlds, groups[g].n_worlds, dt, vel_iters, pos_iters);
+        for (int g = 0; g < n_groups; ++g) // (a group whose steps go in one launch: queued whole)
+            if (plans[g].train) {
+                int rc = tiles_launch_train(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin, n_steps);
+                if (rc != REM2D_OK) return rc;
+            }
         for (int l = 0; l < n_steps; ++l)
             for (int g = 0; g < n_groups; ++g)
-                tiles_launch_step(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin);
+                if (!plans[g].train) tiles_launch_step(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin);
         HIP_TRY(hipGetLastError());
     } else {
         for (int g = 0; g < n_groups; ++g) {
@@ -1109,7 +1177,14 @@ extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_gr
     if (tiles)
         for (int g = 0; g < n_groups; ++g) SHAPES_TRY(groups[g].worlds, groups[g].n_worlds);
     hipStream_t origin = (hipStream_t)stream;
-    if (!(flags & REM2D_STEP_GRAPH) || timing || !tiles)
+    bool train = false; // (a step train is one launch per call already, and sizes its flag buffer while it is queued: never captured)
+    if (tiles)
+        for (int g = 0; g < n_groups; ++g) {
+            TilePlan P;
+            tiles_plan(P, groups[g].worlds, groups[g].n_worlds, dt, vel_iters, pos_iters);
+            train = train || P.train;
+        }
+    if (!(flags & REM2D_STEP_GRAPH) || timing || !tiles || train)
         return groups_enqueue(groups, n_groups, n_steps, dt, vel_iters, pos_iters, origin, tiles);
 
     // ---- graph replay ----

@@ -578,8 +578,8 @@ DEV void toi_scan_body(const State &S, const Terrain &T, const StepArgs &A, unsi
                   LF(L_HX), LF(L_HY), LI(L_AWAKE), LI(L_CCOUNT));
 }
 // the TOI solve of one body (lane gl of the world) by the G lanes that carry it, then the step's bookkeeping if it is a root
-template <int K>
-DEV void toi_heavy_one(const State &S, const Terrain &T, const StepArgs &A, unsigned gl, ToiShared &ts, int sub, int G) {
+template <int K, int COLS = WAVE>
+DEV void toi_heavy_one(const State &S, const Terrain &T, const StepArgs &A, unsigned gl, ToiSharedT<COLS> &ts, int sub, int G) {
     const unsigned env = gl / K;
     const int shape = LI(L_SHAPE);
     const unsigned wb = (unsigned)SCR_SWEEP_BASE * S.Lp + gl;

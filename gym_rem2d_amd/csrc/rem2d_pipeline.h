@@ -20,19 +20,26 @@
 // ---------------------------------------------------------------------------------------------------
 // pre: Modular2D.step's controller sweep, b2World::Step up to (not including) the warm start
 // ---------------------------------------------------------------------------------------------------
-template <int K>
+// INTILE (rem2d_step_train_kernel: pre, the velocity tile, the position block and the TOI solve of the same 64 lanes by one
+// workgroup): the lane group takes the creature the velocity tile and the position block of this workgroup take -- slot s of the
+// grid is creature order[s] -- and has no grid-wide chores (no TOI work list; REM2D_FLAG_RETILE worlds, whose order is copied by
+// this kernel for the whole grid, keep the launches of their own).
+template <int K, bool INTILE = false>
 DEV void pre_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) {
     const int lane = threadIdx.x;
-    const unsigned gl = block * WAVE + lane;
-    const unsigned env = gl / K;
     const int base = lane & ~(K - 1);
     const int sub = lane & (K - 1);
+    const unsigned slot = (block * WAVE + lane) / K;
+    const unsigned env = (INTILE && (S.flags & REM2D_STATE_ORDERED)) ? (unsigned)S.order[slot] : slot;
+    const unsigned gl = env * K + sub;
     const unsigned Lp = S.Lp;
-    if (gl == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
-    // creature order of the post kernel: what post wrote in the last step becomes what it reads in this one
-    if (S.flags & REM2D_FLAG_RETILE) {
-        if (gl < S.Np) S.order[gl] = S.order[S.Np + gl];
-        if (gl == 0) { S.order[2 * S.Np] = 0; S.order[2 * S.Np + 1] = 0; }
+    if (!INTILE) {
+        if (gl == 0) S.toiWork[0] = 0; // work list of the TOI kernels that follow
+        // creature order of the post kernel: what post wrote in the last step becomes what it reads in this one
+        if (S.flags & REM2D_FLAG_RETILE) {
+            if (gl < S.Np) S.order[gl] = S.order[S.Np + gl];
+            if (gl == 0) { S.order[2 * S.Np] = 0; S.order[2 * S.Np + 1] = 0; }
+        }
     }
     if (S.flags & REM2D_FLAG_SKIP_FROZEN) { // evaluate() has left its loop for every creature of this wavefront
         if (__all(EI(E_FROZEN) != 0 ? 1 : 0)) {

@@ -498,17 +498,22 @@ struct LaneBody { float px, py, ang, vx, vy, w, sleepT; int awake, cCount, err, 
 // The TOI island's manifolds (<= KT per body) live in LDS while the sub-step is solved: the 20 TOI position
 // iterations and the constraint set-up read them again and again, and a round trip to the scratch arena in HBM/L2
 // per word was most of this kernel's latency chain.  [word][lane]: conflict-free for a wavefront.
-struct ToiShared { float m[KT * SCR_WORDS][WAVE]; };
-DEV void island_store(ToiShared &ts, int lane, int t, const Manifold &m) {
-    float (*w)[WAVE] = ts.m + t * SCR_WORDS;
-    w[0][lane] = __int_as_float(m.type | (m.count << 8));
-    w[1][lane] = m.ln.x; w[2][lane] = m.ln.y; w[3][lane] = m.lp.x; w[4][lane] = m.lp.y;
-    w[5][lane] = m.p0.x; w[6][lane] = m.p0.y; w[7][lane] = m.p1.x; w[8][lane] = m.p1.y;
+// COLS = WAVE: a column per lane (a wavefront may carry several bodies); COLS = 1: the whole wavefront carries ONE body, its lanes
+// hold copies of each other and share one column (the in-wavefront solve of rem2d_step_queue_kernel: 216 B instead of 13.8 KB).
+template <int COLS> struct ToiSharedT { float m[KT * SCR_WORDS][COLS]; };
+typedef ToiSharedT<WAVE> ToiShared;
+template <int COLS> DEV void island_store(ToiSharedT<COLS> &ts, int lane, int t, const Manifold &m) {
+    float (*w)[COLS] = ts.m + t * SCR_WORDS;
+    const int c = lane & (COLS - 1);
+    w[0][c] = __int_as_float(m.type | (m.count << 8));
+    w[1][c] = m.ln.x; w[2][c] = m.ln.y; w[3][c] = m.lp.x; w[4][c] = m.lp.y;
+    w[5][c] = m.p0.x; w[6][c] = m.p0.y; w[7][c] = m.p1.x; w[8][c] = m.p1.y;
 }
-#define IW(t, k) (ts.m[(t) * SCR_WORDS + (k)][lane])
+#define IW(t, k) (ts.m[(t) * SCR_WORDS + (k)][lane & (COLS - 1)])
+template <int COLS>
 DEV LaneBody solve_toi_lane(const State &S, const Terrain &T, unsigned gl, int shape, float hx, float hy, float mB, float iB,
                                                 float h, int velIters, float c0x, float c0y, float a0, LaneBody B,
-                                                ToiShared &ts, int lane, int sub, int G) {
+                                                ToiSharedT<COLS> &ts, int lane, int sub, int G) {
     // sub / G: the G lanes (a power of two, G-aligned) that carry this body.  All of them run this function on the same
     // values -- so every store below writes the same word G times, harmless -- except in the alpha pass, where lane `sub`
     // takes the pair slots sub, sub + G, ...: the b2TimeOfImpact calls of a body run side by side instead of one after

@@ -753,4 +753,95 @@ __global__ __launch_bounds__(WAVE * REM2D_VELPOST_WAVES, 4) void rem2d_velpost_k
     BATCH_DISPATCH(post_only_body, sh.p)
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The step TRAIN: all steps of a call in ONE launch, without a launch boundary between two steps or two phases of a step.
+// One workgroup (a wavefront) per item (step, block), in launch order: item = step * nPad + slot.  It runs `pre` for the creatures
+// of the block's slots (in the creature order), their velocity tile(s), their position block and -- continuous physics -- the TOI
+// solve of the block's own bodies (the whole wavefront per body, one after the other: what rem2d_toi_heavy_multi_kernel does for
+// its work list), then publishes "step s of block b done"; the item of the block's next step waits for that flag first.
+//   * No deadlock: the workgroup of a block's previous step has a lower index, so it was dispatched earlier and runs or is done
+//     (the forward-progress assumption of every decoupled look-back scan); every wait is bounded by the clock anyway.
+//   * Hand-over inside an XCD: nPad = the blocks rounded up to a multiple of 8, workgroups go round-robin over the 8 XCDs, so all
+//     steps of a block run on ONE XCD and its state never has to leave that XCD's L2: publishing = the stores have arrived
+//     (s_waitcnt) + a flag, the waiter drops its CU's L1 (buffer_inv sc1).  An agent-scope release (an L2 write-back per item) costs
+//     3 % (profiles/r05_step_train.txt).  The flag carries the publisher's XCC_ID and the waiter compares: a hand-over from another
+//     XCD or a wait that ran into its limit sets REM2D_ERR_HANDOVER on the block's creatures -- never a silent wrong result.
+//   * Same device functions, same order per creature as the separate launches: same bits (the parity suite runs this launch).
+// A wavefront slot is refilled one block-step at a time and no launch waits for its slowest tile: config 3 1.30 -> 1.02 ms per
+// env-step.  128 VGPRs; the TOI solve (226 VGPRs in its own kernel) spills here (656 spilled VGPRs, all in the post / TOI part: 1 %
+// of the bodies go through it), 1 KB of LDS per wavefront (its island's manifolds in one column).
+// ---------------------------------------------------------------------------------------------------
+template <int K> DEV void pre_intile_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block) { pre_body<K, true>(S, T, A, block); }
+// post + (continuous physics) the TOI solve of this block's own bodies, one after the other, by the whole wavefront (G = 64 lanes
+// per body, one LDS column); a failed hand-over (`bad`) is flagged on every creature of the block
+template <int K>
+DEV void post_toi_body(const State &S, const Terrain &T, const StepArgs &A, unsigned block, PosShared &psh, ToiSharedT<1> &ts1, int bad) {
+    const bool heavy = post_body<K, true>(S, T, A, block, psh);
+    const int lane = threadIdx.x;
+    const unsigned slot = (block * WAVE + lane) / K;
+    const unsigned env = (S.flags & REM2D_STATE_ORDERED) ? (unsigned)S.order[slot] : slot;
+    if (bad && (lane & (K - 1)) == 0) EI(E_ERR) = EI(E_ERR) | REM2D_ERR_HANDOVER;
+    if (A.defer != 2) return;
+    const unsigned mygl = env * K + (unsigned)(lane & (K - 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unsigned long long hm = __ballot(heavy ? 1 : 0);
+    while (hm) {
+        const int h = __ffsll((long long)hm) - 1;
+        hm &= hm - 1;
+        const unsigned glh = (unsigned)__shfl((int)mygl, h);
+        toi_heavy_one<K, 1>(S, T, A, glh, ts1, lane, WAVE);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+#define TRAIN_FLAG_WORDS 16 // flags[0 .. 16) spare, flags[16 + block] = steps done | publisher's XCC_ID << 16
+#define TRAIN_WAIT_TICKS 200000000ull // 2 s of the 100 MHz clock: a hand-over that never comes must not hang the GPU
+__global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, StepArgs A, Vel4Args V, int *flags, unsigned nBlocks) {
+    __shared__ VelPostShared sh;
+    __shared__ ToiSharedT<1> ts1;
+    const unsigned nPad = (nBlocks + 7u) & ~7u;
+    const unsigned item = blockIdx.x;
+    const int step = (int)(item / nPad);
+    const unsigned slot = item % nPad;
+    if (slot >= nBlocks) return;
+    const unsigned blk = nBlocks - 1 - slot; // (the widest lane bucket, last in the batch, holds the long tiles: first)
+    const unsigned xcd = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u; // HW_REG_XCC_ID[3:0]
+    int bad = 0;
+    if (step > 0) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int seen;
+            while (((seen = __hip_atomic_load(&flags[TRAIN_FLAG_WORDS + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < step) {
+                __builtin_amdgcn_s_sleep(32);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) { bad = 1; break; }
+            }
+            if ((unsigned)(seen >> 16) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
+        }
+        bad = __builtin_amdgcn_readfirstlane(bad);
+        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); // this CU's L1 forgets what it holds; the XCD's L2 is current
+    }
+    unsigned block = blk;
+    const int b = batch_find(B, block);
+    BATCH_DISPATCH(pre_intile_body)
+    // what pre wrote per block lane is read per tile lane (constraints) below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {
+        const int K = B.lanes[b];
+        const unsigned cpb = (unsigned)(WAVE / K), cap = (unsigned)B.S[b].tileCap; // creatures per block / per tile; cap divides cpb (host)
+        const unsigned t1 = (block + 1) * cpb / cap;
+        for (unsigned t = block * cpb / cap; t < t1 && t < (unsigned)B.S[b].nTiles; ++t) {
+            vel4_body<1, 1, 1, true>(B.S[b], B.T[b].friction, V, t, K, sh.v);
+            lds_sync(); // (the next tile / the position solver reuse the mailbox)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    BATCH_DISPATCH(post_toi_body, sh.p, ts1, bad)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (= s_waitcnt: every store of this item has reached the XCD's L2)
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&flags[TRAIN_FLAG_WORDS + blk], (step + 1) | (int)(xcd << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #endif

@@ -202,6 +202,14 @@ class BatchedModular2D:
         # for >= 98 304 creatures; the stable re-ordering every 50 steps does better there and also pays at 65 536
         # (profiles/r04_lane_fill_experiments.txt), so the flag is an experiment override now (REM2D_RETILE=1)
         retile = os.environ.get("REM2D_RETILE") == "1"
+        # The step train (the library's default launch form for 64-lane tiles, REM2D_OPT_FUSE_VELPOST = 2: all steps of a call in
+        # one launch, block-steps handed from workgroup to workgroup) is ONE in-order train: it wants the whole population in one
+        # group (config 3: 64.8 M env-steps/s with one group, 59 M with two, 39 M with four -- profiles/r05_step_train.txt).
+        opts = _lib.env_options()
+        train = (shape == 3 or (shape is None and _lib.env_tile_shape() == 3)) and not retile and \
+            opts.get("fuse_velpost", 2) == 2 and opts.get("pipeline", 3) == 3 and opts.get("debug", 0) == 0
+        if train and self.step_groups <= 0:
+            groups = 1
         self._world_flags = (self.flags | _lib.FLAG_RETILE) if retile else (self.flags & ~_lib.FLAG_RETILE)
         every = self.rebalance_every
         if every < 0:
@@ -324,13 +332,14 @@ class BatchedModular2D:
             w.set_order(torch.sort((~slow).to(torch.uint8), stable=True).indices, check=False)   # (a sort's indices)
 
     def launch_info(self):
-        """(tile shape, velocity tiles and position iterations in one launch?) of the first step group -- the library's own
-        answer (rem2d_worlds_launch_info); for tools that name kernels, results never depend on it."""
+        """(tile shape, launch form) of the first step group -- the library's own answer (rem2d_worlds_launch_info: 2 = the step
+        train, 1 = velocity tiles and position iterations in one launch per step, 0 = two launches); for tools that name
+        kernels, results never depend on it."""
         idx = self.groups[0] if self.groups else list(range(len(self.worlds)))
         arr = (C.c_void_p * len(idx))(*[self.worlds[i][0].h for i in idx])
         shape, fused = C.c_int32(), C.c_int32()
         _lib.check(_lib.lib(self.wide).rem2d_worlds_launch_info(arr, len(idx), C.byref(shape), C.byref(fused)), self.wide)
-        return shape.value, bool(fused.value)
+        return shape.value, int(fused.value)
 
     def _gather(self, name, out):
         if len(self.worlds) == 1 and not self._compacted:

@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 9 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+#define REM2D_ABI_VERSION 10 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
                                7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar;
-                               9: + rem2d_build_id, rem2d_mutate_trees, count-only compilers (out == NULL); worlds of tile shapes 0 and 2 are refused in one launch */
+                               9: + rem2d_build_id, rem2d_mutate_trees, count-only compilers (out == NULL); worlds of tile shapes 0 and 2 are refused in one launch;
+                               10: REM2D_OPT_FUSE_VELPOST = 2 (the step train, the new default), REM2D_ERR_HANDOVER, rem2d_worlds_launch_info reports 2 for it */
 
 enum {
     REM2D_OK = 0,
@@ -128,6 +129,8 @@ enum { REM2D_DT_F32 = 0, REM2D_DT_I32 = 1, REM2D_DT_F64 = 2 };
 /* error bits in REM2D_F_ERR */
 #define REM2D_ERR_PAIR_OVERFLOW 1   /* more than REM2D_CONTACT_SLOTS fat-AABB pairs on a body */
 #define REM2D_ERR_SOLVER_OVERFLOW 2 /* more than REM2D_SOLVER_SLOTS touching contacts on a body */
+#define REM2D_ERR_HANDOVER 4        /* step train (REM2D_OPT_FUSE_VELPOST = 2): a block's previous step was published from another XCD, or a
+                                      wait for it ran into its 2 s limit -- the creature's state is not to be trusted */
 
 int rem2d_abi_version(void);
 /* Identity of this build: the hash of the library's sources (gym_rem2d_amd/csrc/, this header) and compile flags that the
@@ -140,9 +143,9 @@ const char *rem2d_last_error(void);
 int rem2d_capacity(int32_t *contact_slots, int32_t *solver_slots);
 /* How a step of these worlds (one step group: what rem2d_worlds_step would take) is launched -- for tools that name kernels
  * (bench.py, profiles); results never depend on it.  tile_shape: 3 / 1 / 0 = 64 / 128 / 256 bodies per tile of the velocity
- * kernel; fused_velpost: 1 = the velocity tiles and the position iterations of a 64-lane block share one launch
- * (rem2d_velpost_kernel: pre -> velpost -> toi_heavy), 0 = rem2d_vel4_kernel and rem2d_post_multi_kernel.  Either pointer may
- * be NULL. */
+ * kernel; fused_velpost: 2 = the step train (rem2d_step_train_kernel: all steps of a call and all phases of a step in one launch),
+ * 1 = the velocity tiles and the position iterations of a 64-lane block share one launch per step (rem2d_velpost_kernel: pre ->
+ * velpost -> toi_heavy), 0 = rem2d_vel4_kernel and rem2d_post_multi_kernel.  Either pointer may be NULL. */
 int rem2d_worlds_launch_info(rem2d_world *const *worlds, int32_t n_worlds, int32_t *tile_shape, int32_t *fused_velpost);
 
 /* Bytes of device memory the caller must provide for a world of this shape. */
@@ -229,7 +232,10 @@ int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream
  * no environment variable; a host that wants experiment overrides sets them here (gym_rem2d_amd._lib maps REM2D_* variables
  * onto these calls for bench.py and tools/).  The options of the FIRST world of a step group steer that group's launches.
  *   REM2D_OPT_PIPELINE        3 (default): pre -> velocity tiles -> position kernel; 0: the fused body-per-lane step kernel
- *   REM2D_OPT_FUSE_VELPOST    1 (default): velocity tiles + position iterations of a 64-lane block in one launch; 0: two
+ *   REM2D_OPT_FUSE_VELPOST    2 (default): the step train -- all steps of a call in ONE launch, a workgroup per (step, 64-lane block)
+ *                             runs pre, the velocity tile, the position block and the TOI solve of its own bodies and hands the
+ *                             block to its next step through a flag (rem2d_step_train_kernel; 64-lane tiles, not REM2D_FLAG_RETILE);
+ *                             1: velocity tiles + position iterations of a 64-lane block in one launch per step; 0: two
  *   REM2D_OPT_PRIO            s_setprio mask, default 5: bit 1 slow velocity tiles, bit 4 the TOI solve's wavefronts; 0 off
  *   REM2D_OPT_PRIO_T1 / _T2   slot-cost thresholds (7 per tick + 10 per contact sub-slot) for priority 1 / 3, default 60 / 75
  *   REM2D_OPT_HEAVY_PER_WAVE  bodies of the TOI work list per wavefront, 1..64, default 1

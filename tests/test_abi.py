@@ -36,7 +36,7 @@ def test_field_table_matches_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 9
+    assert L.rem2d_abi_version() == 10
     assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
     # a wide world's arena is laid out for its own slot count
     big = lib.WorldCfg(4096, 8, 0, 0)
@@ -116,5 +116,5 @@ def test_build_identity(lib, tmp_path, monkeypatch):
         lib.lib()
     # an experiment's variant build named through REM2D_LIB_PATH is exempt (tools/build_variant.sh)
     monkeypatch.setenv("REM2D_LIB_PATH", lib.LIB_PATH)
-    assert lib.lib().rem2d_abi_version() == 9
+    assert lib.lib().rem2d_abi_version() == 10
     monkeypatch.setattr(lib, "_lib", None)

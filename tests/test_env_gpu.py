@@ -127,20 +127,26 @@ def test_groups_step_one_call_and_graph_replay(need_gpu, oracle, rough_terrain):
     for k in sorted(groups):
         m = Morphology.from_specs([specs[e] for e in groups[k]], k)
         ref[groups[k]] = oracle.batch_run(ot, m.as_dict(), T, n_threads=8, flags=oracle.FLAG_CONTINUOUS)["fitness"]
-    for n_groups, graph, rebalance in ((1, False, 0), (3, False, 0), (4, False, 0), (4, True, 0), (3, True, 0), (4, True, 7)):
+    # form 2 = the step train (the default), 1 = a launch sequence per step (what a hipGraph replays)
+    for n_groups, graph, rebalance, form in ((1, False, 0, 2), (3, False, 0, 2), (4, False, 7, 2), (4, True, 0, 2), (1, False, 0, 1), (4, False, 0, 1),
+                                             (4, True, 0, 1), (3, True, 0, 1), (4, True, 7, 1)):
         env = BatchedModular2D(seed=4, flags=_lib.FLAG_CONTINUOUS)
         env.step_groups = n_groups
         env.use_graph = graph
         env.rebalance_every = rebalance   # (under a graph the re-ordering launches of the captured call are replayed with it)
         env.reset_specs(specs)
         assert len(env.groups) == n_groups
+        for w, _ in env.worlds:
+            w.set_option("fuse_velpost", form)
         if not any(k in os.environ for k in ("REM2D_TILE_SHAPE", "REM2D_FUSE_VELPOST", "REM2D_PIPELINE", "REM2D_RETILE")):
-            # rem2d_worlds_launch_info: 64-body tiles, velocity tiles + position iterations in one launch
-            assert env.launch_info() == (3, True)
+            # rem2d_worlds_launch_info: 64-body tiles; as a step train (all steps of a call in one launch; with REM2D_STEP_GRAPH
+            # the train is queued as it is -- one launch per call needs no graph) or velocity tiles + position iterations in one
+            # launch per step
+            assert env.launch_info() == (3, form)
         for n in (1, 24, 25, 25, 25, 25, 25):      # (25 five times: the graph of that length is captured once, replayed four times)
             env.step(n)
         torch.cuda.synchronize()
-        assert np.array_equal(env.fitness.cpu().numpy(), ref), (n_groups, graph, rebalance)
+        assert np.array_equal(env.fitness.cpu().numpy(), ref), (n_groups, graph, rebalance, form)
         assert bool((env.steps == T).all()) and int(env.errors().max()) == 0
         env.close()
     L = _lib.lib()
@@ -530,7 +536,7 @@ def test_bench_population_exactly_as_benched_equals_the_oracle(need_gpu, oracle,
     assert "65536 random L-System creatures (seeds 0..65535" in desc and [m.lanes for m in morphs] == [2, 4, 8, 16]
     dev = torch.device("cuda", 0)
     env = bench.make_env(morphs, dev, False, True, False)
-    assert len(env.groups) == 4 and len(env.worlds) == 16 and env.launch_info() == (3, True)
+    assert len(env.groups) == 1 and len(env.worlds) == 4 and env.launch_info() == (3, 2)   # (the step train: one group)
     T = 120
     bench.stepper(env, 25)(T)
     torch.cuda.synchronize()

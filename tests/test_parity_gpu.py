@@ -337,7 +337,7 @@ def test_post_kernel_retiling_keeps_every_bit(gpu, oracle, rough_terrain, skip_f
     w.close()
 
 
-@pytest.mark.parametrize("launch", ["velpost", "two_launches", "tiles_128_bodies", "tiles_128_static", "tiles_256_static",
+@pytest.mark.parametrize("launch", ["step_train", "velpost", "two_launches", "tiles_128_bodies", "tiles_128_static", "tiles_256_static",
                                     "fused_step_kernel"])
 def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch):
     """rem2d_world_set_order: slot e of the velocity tiles / position blocks handles creature order[e].  Any permutation --
@@ -350,7 +350,7 @@ def test_host_creature_order_keeps_every_bit(gpu, oracle, rough_terrain, launch)
     from gym_rem2d_amd.compiler import Morphology
     specs = [s for s in synthetic.lsystem_specs(range(400), mutate_odd=True) if 3 <= s.n_bodies <= 8]
     morph = Morphology.from_specs(specs, 8)
-    opts = {"two_launches": {"fuse_velpost": 0}, "fused_step_kernel": {"pipeline": 0}}.get(launch)
+    opts = {"two_launches": {"fuse_velpost": 0}, "velpost": {"fuse_velpost": 1}, "fused_step_kernel": {"pipeline": 0}}.get(launch)
     w = gpu(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
     w.set_terrain(rough_terrain)
     shape = {"tiles_128_bodies": 1, "tiles_128_static": 4, "tiles_256_static": 0}.get(launch)
@@ -460,7 +460,8 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
             ow.env_step_ex(1.0 / 50, vel_iters, pos_iters)
         refs.append((ow.bodies(), ow.position_iterations))
     # the default 64-body tiles, the 128-body flexible and static shapes, velocity tiles + position blocks in two launches
-    for shape, opts in ((None, None), (1, None), (4, None), (None, {"fuse_velpost": 0}), (None, {"rebalance": 9})):
+    for shape, opts in ((None, None), (1, None), (4, None), (None, {"fuse_velpost": 0}), (None, {"fuse_velpost": 1}), (None, {"rebalance": 9}),
+                        (None, {"rebalance": 9, "fuse_velpost": 1})):
         w = gpu(morph.n_envs, morph.lanes, flags, options=opts)
         w.set_terrain(rough_terrain)
         w.reset(morph, tile_shape=shape)
@@ -477,9 +478,10 @@ def test_step_ex_iteration_counts_bit_exact(gpu, oracle, rough_terrain, vel_iter
 
 
 @pytest.mark.parametrize("variant", [{"pipeline": 0}, {"tile_shape": 0}, {"tile_shape": 1}, {"tile_shape": 2}, {"tile_shape": 4}, {"fuse_velpost": 0},
-                                     {"prio": 0, "heavy_per_wave": 2}],
+                                     {"fuse_velpost": 1}, {"prio": 0, "heavy_per_wave": 2, "fuse_velpost": 1}, {"prio": 0}],
                          ids=["fused_step_kernel", "tiles_256_bodies", "tiles_128_bodies", "tiles_192_bodies", "tiles_128_bodies_static_sets",
-                              "velocity_and_position_in_two_launches", "no_issue_priority_two_toi_bodies_per_wavefront"])
+                              "velocity_and_position_in_two_launches", "one_launch_per_step_velpost",
+                              "no_issue_priority_two_toi_bodies_per_wavefront", "step_train_without_issue_priority"])
 def test_other_formulations_match_committed_digests(gpu, variant):
     """The library's switches are per-world launch options (rem2d_world_set_option / rem2d_world_set_tile_shape; it reads no
     environment variable), so every other formulation runs in this very process: the fused body-per-lane kernel of round 1
@@ -517,8 +519,8 @@ def test_option_argument_errors(gpu):
     from gym_rem2d_amd import _lib
     w = gpu(4, 4, 0)
     L = _lib.lib()
-    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 1, 5, 60, 75, 1, 0, 0]     # the documented defaults
-    for key, bad in ((0, 1), (0, 2), (1, 2), (5, 0), (5, 65), (2, -1), (99, 0), (-1, 0)):
+    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 2, 5, 60, 75, 1, 0, 0]     # the documented defaults
+    for key, bad in ((0, 1), (0, 2), (1, 3), (5, 0), (5, 65), (2, -1), (99, 0), (-1, 0)):
         assert L.rem2d_world_set_option(w.h, key, bad) == -1, (key, bad)
     assert b"option" in L.rem2d_last_error()
     assert L.rem2d_world_get_option(w.h, 99, C.byref(C.c_int32())) == -1
