@@ -114,6 +114,19 @@ def valu_issue(n_groups):
     return None
 
 
+def train_counters():
+    """The committed counter passes of the step train (tools/r05_train_profile.sh -> profiles/r05_step_train_counters.json): per
+    env-step of the headline population -- HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) and VALU
+    wave-instructions."""
+    path = os.path.join(ROOT, "profiles", "r05_step_train_counters.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d, os.path.relpath(path, ROOT)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def build_population(workload, n_envs, first):
     """Host-side synthetic input, first stage, BEFORE the GPU is initialised and before torch is imported (uses a fork
     pool): the genomes of the population.  finish_population() turns them into lane-bucket batches."""
@@ -377,7 +390,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank steps its own --envs creatures; strong: --envs creatures in all, split over the ranks")
     ap.add_argument("--envs", type=int, default=None, help="creatures per GPU (weak) / in all (strong); default: config size")
-    ap.add_argument("--steps-per-launch", type=int, default=25,
+    ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="env-steps per C-ABI step call (one call = that many kernel sequences queued on the streams)")
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed steps right after reset so that creatures have landed (spawn is 2 m up)")
@@ -572,10 +585,25 @@ def main():
     achieved_step = bytes_per_step * timing_steps / (ms_step * 1e-3) / 1e9 if ms_step > 0 else None
     valu = flops_per_step * timing_steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     headline = args.workload == "lsystem" and not args.discrete and n_envs == 65536
-    traffic_bytes, traffic_src = pmc_traffic(kname) if headline else (None, None)
-    traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
-    traffic_all = pmc_traffic_all() if headline else None
-    issue = valu_issue(n_groups) if headline and pipeline == 3 else None
+    if headline and fused_velpost == 2:
+        # the step train: one kernel holds the whole step; its counters are booked per env-step of the population (a launch
+        # covers as many steps as the ABI call asks for), so traffic = bytes per env-step x the steps the timing pass ran / its time
+        tc, traffic_src = train_counters()
+        pe = tc["per_env_step"] if tc else {}
+        traffic_bytes = pe.get("hbm_bytes")
+        traffic = traffic_bytes * timing_steps / (ms * 1e-3) / 1e9 if (traffic_bytes and ms > 0) else None
+        traffic_all = {"bytes_per_env_step": traffic_bytes, "bytes_per_env_step_raw": pe.get("hbm_bytes_raw"),
+                       "algorithmic_bytes_per_env_step": bytes_per_step, "source": traffic_src} if traffic_bytes else None
+        issue = None
+        if pe.get("SQ_INSTS_VALU") and tc.get("step_groups") == n_groups:
+            issue = {"wave_instructions_per_env_step": pe["SQ_INSTS_VALU"], "peak_wave_instructions_per_s": 860e9,
+                     "active_lanes_per_valu_inst": tc.get("active_lanes_per_valu_inst"),
+                     "source": "%s (per env-step of this population), profiles/r02_b_ubench_valu_latency.txt" % traffic_src}
+    else:
+        traffic_bytes, traffic_src = pmc_traffic(kname) if headline else (None, None)
+        traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None
+        traffic_all = pmc_traffic_all() if headline else None
+        issue = valu_issue(n_groups) if headline and pipeline == 3 else None
     if issue:
         issue["achieved_wave_instructions_per_s"] = issue["wave_instructions_per_env_step"] * args.steps / dt
         issue["frac"] = issue["achieved_wave_instructions_per_s"] / issue["peak_wave_instructions_per_s"]
@@ -646,8 +674,11 @@ def main():
                                     "of its own bodies, block-steps handed over through flags inside an XCD)" if fused_velpost == 2 else
                                     "tile (pre / velpost = vel4 + post + toi_scan / toi_heavy)" if fused_velpost else
                                     {3: "tile (pre / vel4 / post+toi_scan / toi_heavy)", 0: "fused step kernel + TOI kernels"}[pipeline]),
-                       "kernel_launches_per_env_step_per_group": ((4 if not args.discrete else 3) - (1 if fused_velpost else 0))
+                       "kernel_launches_per_env_step_per_group": (None if fused_velpost == 2 else
+                                                                  (4 if not args.discrete else 3) - (1 if fused_velpost else 0))
                        if pipeline == 3 else None,
+                       # (the step train: ONE launch per ABI call -- plus one per re-ordering of the creature order inside it)
+                       "kernel_launches_per_abi_call": 1 if fused_velpost == 2 else None,
                        "steps_per_abi_call": spl,
                        "settle_steps": args.settle,
                        "velocity_iterations": 180, "position_iterations": 60, "dt": 0.02,

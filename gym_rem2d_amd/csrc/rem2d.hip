@@ -132,6 +132,7 @@ struct rem2d_world {
     uint64_t epoch;            // bumped whenever something the kernel arguments embed changes (graph replay key)
     int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
     int64_t stepsQueued;          // env-steps queued so far (the cadence of REM2D_OPT_REBALANCE)
+    int64_t stepsAtOrder;         // ... at the step train's last re-ordering launch
     int *trainFlags; size_t trainCap; // rem2d_step_train_kernel's hand-over flags (device; grown on demand, as the first world of a launch)
     bool hostOrder;               // rem2d_world_set_order installed an order (REM2D_STATE_ORDERED = hostOrder || REBALANCE > 0)
 };
@@ -275,6 +276,7 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->epoch = next_epoch();
     for (int k = 0; k < REM2D_OPT_COUNT; ++k) w->opt[k] = kOptDefault[k];
     w->stepsQueued = 0;
+    w->stepsAtOrder = 0;
     w->hostOrder = false;
     bind_state(w);
     w->S.scr = nullptr;
@@ -893,26 +895,27 @@ static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
         w0->trainCap = need;
     }
     const unsigned nPad = (P.blocks + 7u) & ~7u;
+    // The creature order is re-made in front of a launch once N (REM2D_OPT_REBALANCE) or more steps have run since the last time --
+    // a cadence in launches, not in steps: a call is cut only where it is itself longer than N steps, never because a multiple
+    // of N falls inside it (two short trains drain twice).  Any cadence gives the same bits.
     int l = 0;
     while (l < n_steps) {
         int seg = n_steps - l;
         if ((unsigned long long)nPad * (unsigned)seg > 0x7fffffffull) seg = (int)(0x7fffffffull / nPad);
         for (int i = 0; i < P.nw; ++i) {
             const int every = P.ws[i]->opt[REM2D_OPT_REBALANCE];
-            if (every > 0) {
-                const int to_next = every - (int)(P.ws[i]->stepsQueued % every);
-                seg = seg < to_next ? seg : to_next;
-            }
+            if (every > 0 && seg > every) seg = every;
         }
         const bool timedStep = w0->timing && w0->evUsedStep < (int)w0->evPoolStep.size() &&
                                hipEventRecord(w0->evPoolStep[w0->evUsedStep].first, st) == hipSuccess;
         for (int i = 0; i < P.nw; ++i) {
             rem2d_world *w = P.ws[i];
             const int every = w->opt[REM2D_OPT_REBALANCE];
-            if (every > 0 && w->stepsQueued > 0 && w->stepsQueued % every == 0 && (w->S.flags & REM2D_STATE_ORDERED)) {
+            if (every > 0 && w->stepsQueued > 0 && w->stepsQueued - w->stepsAtOrder >= every && (w->S.flags & REM2D_STATE_ORDERED)) {
                 int threads = WAVE;
                 while (threads < REBALANCE_MAX_THREADS && threads * 256 < w->cfg.n_envs) threads *= 2;
                 hipLaunchKernelGGL(rem2d_rebalance_kernel, dim3(1), dim3(threads), 0, st, w->S, P.A.posIters);
+                w->stepsAtOrder = w->stepsQueued;
             }
             w->stepsQueued += seg;
         }

@@ -242,7 +242,9 @@ int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream
  *   REM2D_OPT_DEBUG           diagnostic builds only (-DREM2D_V4_PROBES), default 0
  *   REM2D_OPT_REBALANCE       N > 0: every N env-steps the library re-makes the world's creature order on the device (what
  *                             rem2d_world_set_order installs from the host: the creatures that used every position iteration in
- *                             the last step first, a stable partition); 0 (default) off.  Refused with REM2D_FLAG_RETILE
+ *                             the last step first, a stable partition); 0 (default) off.  Refused with REM2D_FLAG_RETILE.  The step
+ *                             train re-orders in front of a launch once N or more steps have run since the last time (a call is
+ *                             cut only where it is itself longer than N steps)
  * Returns REM2D_E_INVALID for an unknown key or a value outside the option's range. */
 enum {
     REM2D_OPT_PIPELINE = 0, REM2D_OPT_FUSE_VELPOST, REM2D_OPT_PRIO, REM2D_OPT_PRIO_T1, REM2D_OPT_PRIO_T2,
