@@ -49,7 +49,7 @@ def fuzz(rounds, seed, creatures, report=print):
                 if op == 0:
                     v = int(rng.choice([0, 3])); w.set_option("pipeline", v); log.append("pipeline=%d" % v)
                 elif op == 1:
-                    v = int(rng.integers(0, 2)); w.set_option("fuse_velpost", v); log.append("fuse=%d" % v)
+                    v = int(rng.integers(0, 3)); w.set_option("fuse_velpost", v); log.append("fuse=%d" % v)   # (2 = the step train)
                 elif op == 2:
                     sh = int(rng.integers(0, 5))
                     if rng.integers(0, 2):   # the library's default plan for the shape
