@@ -459,10 +459,10 @@ extern "C" int rem2d_plan_tiles_shape(const int32_t *parent, const int32_t *jrou
     const int maxLanes = sh.passes * WAVE;
     if (n_envs <= 0 || n_padded < n_envs || lanes <= 0 || lanes > maxLanes) return fail(REM2D_E_INVALID, "plan_tiles: bad shape");
     if (max_creatures <= 0) {
-        // (64-lane tiles: two-lane creatures, 32 to a tile, are faster 16 to a tile -- 46.8 vs 46.4 M on config 3, 55 vs 49 M on
-        // config 4; the wider shapes are taken where instruction issue limits, and more tiles are more instructions)
-        const int shapeId = tile_shape_sel < 0 ? DEFAULT_TILE_SHAPE : tile_shape_sel;
-        max_creatures = shapeId == 3 ? 16 : 32;
+        // (fewer, fuller tiles are fewer wave-instructions: with the step train, which issues at 0.9 of the chip's peak, two-lane
+        // creatures 32 to a 64-lane tile are +1.0 % on config 3 over 16 to a tile, 8 to a tile -28 %; under the per-step launches
+        // of rounds 2-4, bound by their chain, 16 was the better cap: 46.8 vs 46.4 M then)
+        max_creatures = 32;
     }
     const int capBodies = maxLanes / lanes; // creatures per tile by lanes
     const int cap = max_creatures < capBodies ? max_creatures : capBodies;

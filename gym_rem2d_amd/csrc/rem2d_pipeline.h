@@ -422,8 +422,8 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 
 // ---------------------------------------------------------------------------------------------------
 // Creature order by current cost, made on the device (REM2D_OPT_REBALANCE): a STABLE counting sort of the world's creatures
-// by cost class -- those that used every position iteration in the last step first, in their static order, the others behind
-// them in theirs -- written to both halves of State::order (what rem2d_world_set_order would install).  One workgroup per
+// by cost class -- those that used every position iteration in the last step first, in their static order, then those that used
+// three or more, then the rest, each class in its static order -- written to both halves of State::order (what rem2d_world_set_order would install).  One workgroup per
 // world: every thread counts the classes of its contiguous chunk, the counts are scanned in LDS, every thread writes its
 // chunk's creatures to their places; launched every N env-steps in front of `pre`.
 // ---------------------------------------------------------------------------------------------------
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 // (a 262 144-creature world of a 1 M-individual generation: 1 024 threads).
 #define REBALANCE_MAX_THREADS 1024
 #ifndef REBALANCE_CLASSES
-#define REBALANCE_CLASSES 2
+#define REBALANCE_CLASSES 3 // (three classes under the step train: +0.7 % on config 3 over two, config 4 unchanged; profiles/r05_step_train.txt)
 #endif
 // cost class of a creature from the position iterations of its last step: 0 = used all of them (the long blocks), ...
 DEV int rebalance_class(int positers, int posIters) {

@@ -194,7 +194,7 @@ int rem2d_world_set_outputs(rem2d_world *w, float *reward_dev, uint8_t *done_dev
 int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, int32_t n_tiles);
 /* Greedy tile plan from a morphology batch (HOST arrays in the layout of rem2d_morph: parent[n_envs*lanes],
  * jround[n_envs*lanes] = round | contact slot << 8 | period << 16).  Consecutive creatures are packed into a tile while
- * it stays within 256 lanes, 64 joints per schedule phase and max_creatures creatures (0: the default, 16 for the 64-lane tile shape and 32 for the wider ones -- keeps the
+ * it stays within 256 lanes, 64 joints per schedule phase and max_creatures creatures (0: the default, 32 -- keeps the
  * tile's touching manifolds within the 128 that rem2d_vel4_kernel holds in registers for typical morphologies).
  * n_padded >= n_envs: creatures [n_envs, n_padded) are empty padding (rem2d_padded_envs).  tile_start_out needs room
  * for n_padded + 1 entries; *n_tiles_out receives the tile count. */
