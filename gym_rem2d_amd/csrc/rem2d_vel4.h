@@ -819,7 +819,9 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
             if ((unsigned)(seen >> 16) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
         }
         bad = __builtin_amdgcn_readfirstlane(bad);
-        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); // this CU's L1 forgets what it holds; the XCD's L2 is current
+        // this CU's vector L1 and the scalar data cache (a 64-lane creature's per-creature words are uniform loads) forget what they
+        // hold from an earlier step of the block; the XCD's L2 is current
+        asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     unsigned block = blk;
     const int b = batch_find(B, block);
