@@ -34,6 +34,15 @@ def test_field_table_matches_header(lib):
     assert [i.lower() for i in ids] == lib.FIELDS
 
 
+def test_error_bits_match_header(lib):
+    """REM2D_ERR_* of include/rem2d.h are what gym_rem2d_amd._lib names (the step train's hand-over check added REM2D_ERR_HANDOVER
+    in ABI 10: a creature that carries it is re-evaluated or refused like an overflowing one, never trusted)."""
+    hdr = open(os.path.join(ROOT, "include", "rem2d.h")).read()
+    bits = dict((k, int(v)) for k, v in re.findall(r"#define REM2D_ERR_([A-Z_]+) (\d+)", hdr))
+    assert bits == {"PAIR_OVERFLOW": lib.ERR_PAIR_OVERFLOW, "SOLVER_OVERFLOW": lib.ERR_SOLVER_OVERFLOW, "HANDOVER": lib.ERR_HANDOVER}
+    assert sorted(bits.values()) == [1, 2, 4]
+
+
 def test_host_only_entry_points(lib):
     L = lib.lib()
     assert L.rem2d_abi_version() == 10
