@@ -814,7 +814,14 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
             int seen;
             while (((seen = __hip_atomic_load(&flags[TRAIN_FLAG_WORDS + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < step) {
                 __builtin_amdgcn_s_sleep(32);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) { bad = 1; break; }
+                // one wait that ran into the limit ends every later wait of the launch at once (flags[1]): the launch drains in
+                // milliseconds with REM2D_ERR_HANDOVER on what it touched instead of stalling 2 s per item
+                if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) {
+                    __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bad = 1;
+                    break;
+                }
             }
             if ((unsigned)(seen >> 16) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
         }
