@@ -33,13 +33,20 @@ SOLVER_SLOTS = 6
 ERR_PAIR_OVERFLOW = 1
 ERR_SOLVER_OVERFLOW = 2
 ERR_HANDOVER = 4   # (the step train's hand-over check, include/rem2d.h)
+ERR_CAPACITY = ERR_PAIR_OVERFLOW | ERR_SOLVER_OVERFLOW
+
+
+def train_fault(step, every_block=1, drop=False):
+    """Value of the `train_fault` test option (REM2D_OPT_TRAIN_FAULT): the workgroups of step `step` (1-based inside a launch) of
+    the blocks with block % every_block == 0 are told that their hand-over failed / (drop) never get their flag."""
+    return int(step) | (int(every_block) << 16) | ((1 << 30) if drop else 0)
 
 # launch options of a world (include/rem2d.h REM2D_OPT_*, rem2d_world_set_option): no result depends on them
-OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug", "rebalance")
+OPTIONS = ("pipeline", "fuse_velpost", "prio", "prio_t1", "prio_t2", "heavy_per_wave", "debug", "rebalance", "train_fault")
 OPTION_ID = {n: i for i, n in enumerate(OPTIONS)}
 _ENV_OPTIONS = {"REM2D_PIPELINE": "pipeline", "REM2D_FUSE_VELPOST": "fuse_velpost", "REM2D_PRIO": "prio",
                 "REM2D_PRIO_T1": "prio_t1", "REM2D_PRIO_T2": "prio_t2", "REM2D_HEAVY_PER_WAVE": "heavy_per_wave",
-                "REM2D_V4_DBG": "debug", "REM2D_REBALANCE_DEV": "rebalance"}
+                "REM2D_V4_DBG": "debug", "REM2D_REBALANCE_DEV": "rebalance", "REM2D_TRAIN_FAULT": "train_fault"}
 
 
 def env_options():
@@ -132,6 +139,21 @@ class StepGroup(C.Structure):
 
 class Rem2dError(RuntimeError):
     pass
+
+
+class HandoverError(Rem2dError):
+    """A step train launch (REM2D_OPT_FUSE_VELPOST = 2, the default launch form) reported failed hand-overs between the workgroups of
+    consecutive steps: a block's previous step was published from another XCD, or a wait for it ran into its 2 s limit (a GPU shared
+    with another job, a partition mode that changes the workgroup -> XCD mapping).  NOT a contact-capacity problem: the creatures
+    that carry REM2D_ERR_HANDOVER hold a state that cannot be trusted; the remedy is the same creatures on per-step launches
+    (``options={"fuse_velpost": 1}``), which evaluate.run_episode does by itself.  ``failures``: workgroups that reported it."""
+
+    def __init__(self, failures, where=""):
+        self.failures = int(failures)
+        super().__init__("%d hand-over(s) between the workgroups of the step train failed%s: the creatures flagged REM2D_ERR_HANDOVER "
+                         "(env.errors() & 4) hold a state that is not to be trusted -- step them on per-step launches instead "
+                         "(BatchedModular2D(options={'fuse_velpost': 1}) / REM2D_FUSE_VELPOST=1); evaluate.run_episode re-evaluates "
+                         "them that way by itself" % (self.failures, where))
 
 
 # -fno-slp-vectorize: SLP-packing scalar f32 math into v_pk_* costs more register shuffling (v_mov) than it saves here;
@@ -286,7 +308,8 @@ def lib(wide=False):
     L.rem2d_world_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     L.rem2d_world_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rem2d_world_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.rem2d_abi_version() != 10:
+    L.rem2d_world_handover_failures.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    if L.rem2d_abi_version() != 11:
         raise Rem2dError("%s: ABI version mismatch" % os.path.basename(path))
     L.rem2d_build_id.restype = C.c_char_p
     # the library must have been built from the sources beside it (REM2D_LIB_PATH / REM2D_WIDE_LIB_PATH name an experiment's

@@ -133,7 +133,9 @@ struct rem2d_world {
     int32_t opt[REM2D_OPT_COUNT]; // launch options (rem2d_world_set_option); results never depend on them
     int64_t stepsQueued;          // env-steps queued so far (the cadence of REM2D_OPT_REBALANCE)
     int64_t stepsAtOrder;         // ... at the step train's last re-ordering launch
-    int *trainFlags; size_t trainCap; // rem2d_step_train_kernel's hand-over flags (device; grown on demand, as the first world of a launch)
+    unsigned *trainFlags; size_t trainCap; // rem2d_step_train_kernel's hand-over flags (device; grown on demand, as the first world of a launch)
+    unsigned *trainFailures;      // pinned host word: hand-overs of this world's trains that failed (rem2d_world_handover_failures)
+    std::vector<int> evStepCount; // env-steps inside each bracket of evPoolStep (a step train's bracket holds a whole launch)
     bool hostOrder;               // rem2d_world_set_order installed an order (REM2D_STATE_ORDERED = hostOrder || REBALANCE > 0)
 };
 // the kernels go through State::order while the host has installed an order OR the library re-makes one every N steps
@@ -185,9 +187,13 @@ static int default_tile_creatures(const TileShape &shp, int lanes) {
 //   DEBUG          diagnostic builds (-DREM2D_V4_PROBES) only: Vel4Args::dbg
 //   REBALANCE      N > 0: every N env-steps the world's creature order is re-made on the device (rem2d_rebalance_kernel: the
 //                  creatures that used every position iteration first, a stable partition), 0 = off
-static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 2, 5, 60, 75, 1, 0, 0};
-static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0};
-static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 2, 7, 1 << 20, 1 << 20, WAVE, 1 << 30, 1 << 20};
+//   TRAIN_FAULT    test hook of the step train's hand-over check: s | m << 16 [| 1 << 30] -- the items (step s of a launch, s >= 1,
+//                  blocks with block % m == 0; m <= 1: every block) are told that their hand-over failed, or (bit 30) never get
+//                  their flag and wait into the limit.  What the kernels COMPUTE does not change; the creatures carry
+//                  REM2D_ERR_HANDOVER and the world's failure counter moves (tests/test_handover_gpu.py)
+static const int32_t kOptDefault[REM2D_OPT_COUNT] = {3, 2, 5, 60, 75, 1, 0, 0, 0};
+static const int32_t kOptMin[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
+static const int32_t kOptMax[REM2D_OPT_COUNT] = {3, 2, 7, 1 << 20, 1 << 20, WAVE, 1 << 30, 1 << 20, 0x7fffffff};
 
 static uint32_t __float_as_uint_host(float f) {
     uint32_t u;
@@ -278,6 +284,9 @@ extern "C" int rem2d_world_create(const rem2d_world_cfg *cfg, void *state_dev, s
     w->stepsQueued = 0;
     w->stepsAtOrder = 0;
     w->hostOrder = false;
+    w->trainFlags = nullptr;
+    w->trainCap = 0;
+    w->trainFailures = nullptr;
     bind_state(w);
     w->S.scr = nullptr;
     hipError_t e = hipMalloc((void **)&w->S.scr, ((size_t)SCR_TOTAL_WORDS * L.Lp + L.Lp + 64) * sizeof(float));
@@ -544,7 +553,7 @@ static void drain_timing(rem2d_world *w) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             w->accumMsStep += ms;
-            w->launchesStep += 1;
+            w->launchesStep += (size_t)i < w->evStepCount.size() ? w->evStepCount[(size_t)i] : 1;
         }
     }
     w->evUsedStep = 0;
@@ -583,6 +592,7 @@ extern "C" int rem2d_world_destroy(rem2d_world *w) {
     if (w->tilesDev) (void)hipFree(w->tilesDev);
     if (w->terrainBuf) (void)hipFree(w->terrainBuf);
     if (w->trainFlags) (void)hipFree(w->trainFlags);
+    if (w->trainFailures) (void)hipHostFree(w->trainFailures);
     delete w;
     return REM2D_OK;
 }
@@ -880,21 +890,36 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
     if (P.continuous) hipLaunchKernelGGL(rem2d_toi_heavy_multi_kernel, grid, block, 0, st, P.B, P.A);
     if (timedStep) {
         (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
+        if (w0->evStepCount.size() < w0->evPoolStep.size()) w0->evStepCount.resize(w0->evPoolStep.size(), 1);
+        w0->evStepCount[(size_t)w0->evUsedStep] = 1;
         w0->evUsedStep += 1;
     }
 }
 // The step train (rem2d_step_train_kernel): the steps of a call in one launch -- or in one launch per stretch between two
 // re-orderings of the creature order (REM2D_OPT_REBALANCE), which run in front of the stretch they are due for.
-static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
+// (the flag buffer and the failure counter of a train's first world: sized before anything of the launch is queued -- growing frees
+// the old buffer, which waits for the launches that use it)
+static int train_reserve(TilePlan &P) {
     rem2d_world *w0 = P.w0;
     const size_t need = TRAIN_FLAG_WORDS + (size_t)P.blocks;
     if (w0->trainCap < need) {
-        if (w0->trainFlags) HIP_TRY(hipFree(w0->trainFlags)); // (blocks until earlier launches that use it are done)
+        if (w0->trainFlags) HIP_TRY(hipFree(w0->trainFlags));
         w0->trainFlags = nullptr; w0->trainCap = 0;
-        HIP_TRY(hipMalloc(&w0->trainFlags, need * sizeof(int)));
+        HIP_TRY(hipMalloc(&w0->trainFlags, need * sizeof(unsigned)));
         w0->trainCap = need;
     }
+    if (!w0->trainFailures) {
+        HIP_TRY(hipHostMalloc((void **)&w0->trainFailures, sizeof(unsigned), hipHostMallocDefault));
+        *w0->trainFailures = 0u;
+    }
+    return REM2D_OK;
+}
+static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
+    rem2d_world *w0 = P.w0;
+    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.blocks;
+    { int rc = train_reserve(P); if (rc != REM2D_OK) return rc; }
     const unsigned nPad = (P.blocks + 7u) & ~7u;
+    const int fault = w0->opt[REM2D_OPT_TRAIN_FAULT];
     // The creature order is re-made in front of a launch once N (REM2D_OPT_REBALANCE) or more steps have run since the last time --
     // a cadence in launches, not in steps: a call is cut only where it is itself longer than N steps, never because a multiple
     // of N falls inside it (two short trains drain twice).  Any cadence gives the same bits.
@@ -902,6 +927,7 @@ static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
     while (l < n_steps) {
         int seg = n_steps - l;
         if ((unsigned long long)nPad * (unsigned)seg > 0x7fffffffull) seg = (int)(0x7fffffffull / nPad);
+        if (seg > (int)TRAIN_STEP_MASK) seg = (int)TRAIN_STEP_MASK; // (the flag's step field; nPad >= 8 keeps seg below it anyway)
         for (int i = 0; i < P.nw; ++i) {
             const int every = P.ws[i]->opt[REM2D_OPT_REBALANCE];
             if (every > 0 && seg > every) seg = every;
@@ -919,18 +945,20 @@ static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
             }
             w->stepsQueued += seg;
         }
-        HIP_TRY(hipMemsetAsync(w0->trainFlags, 0, need * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(w0->trainFlags, 0, need * sizeof(unsigned), st));
         P.A.nSteps = seg;
         const dim3 grid(nPad * (unsigned)seg), block(WAVE);
         if (w0->timing && w0->evUsed < (int)w0->evPool.size()) {
             hipExtLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, w0->evPool[w0->evUsed].first, w0->evPool[w0->evUsed].second, 0,
-                                  P.B, P.A, P.V, w0->trainFlags, P.blocks);
+                                  P.B, P.A, P.V, w0->trainFlags, P.blocks, fault, w0->trainFailures);
             w0->evUsed += 1;
         } else {
-            hipLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, P.B, P.A, P.V, w0->trainFlags, P.blocks);
+            hipLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, P.B, P.A, P.V, w0->trainFlags, P.blocks, fault, w0->trainFailures);
         }
         if (timedStep) {
             (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
+            if (w0->evStepCount.size() < w0->evPoolStep.size()) w0->evStepCount.resize(w0->evPoolStep.size(), 1);
+            w0->evStepCount[(size_t)w0->evUsedStep] = seg; // (this bracket holds `seg` env-steps)
             w0->evUsedStep += 1;
         }
         l += seg;
@@ -1103,9 +1131,18 @@ static uint64_t mix64(uint64_t h, uint64_t v) {
 
 static int groups_enqueue(const rem2d_step_group *groups, int n_groups, int n_steps, float dt, int vel_iters, int pos_iters,
                           hipStream_t origin, bool tiles) {
+    // (a step train's flag buffer is sized BEFORE the fork: growing it frees the old one, a device-wide wait that does not belong
+    // between a fork and its join, and an error here must not leave forked streams behind)
+    std::vector<TilePlan> plans(tiles ? (size_t)n_groups : (size_t)0);
+    if (tiles)
+        for (int g = 0; g < n_groups; ++g) {
+            tiles_plan(plans[g], groups[g].worlds, groups[g].n_worlds, dt, vel_iters, pos_iters);
+            if (plans[g].train) { int rc = train_reserve(plans[g]); if (rc != REM2D_OK) return rc; }
+        }
     // fork: every group stream waits for what the origin stream has queued so far
     rem2d_world *w00 = groups[0].worlds[0];
     bool forked = false;
+    int rcAll = REM2D_OK; // (an error after the fork still runs the join: no group stream is left un-joined behind an error return)
     for (int g = 0; g < n_groups; ++g) {
         hipStream_t sg = groups[g].stream ? (hipStream_t)groups[g].stream : origin;
         if (sg == origin) continue;
@@ -1118,33 +1155,30 @@ static int groups_enqueue(const rem2d_step_group *groups, int n_groups, int n_st
     if (tiles) {
         // round-robin: step l of every group is queued before step l + 1 of any, so that no group's stream runs dry while
         // the host is still busy queueing another group's whole train (and the groups start together)
-        std::vector<TilePlan> plans((size_t)n_groups);
-        for (int g = 0; g < n_groups; ++g) tiles_plan(plans[g], groups[g].worlds, groups[g].n_worlds, dt, vel_iters, pos_iters);
-        for (int g = 0; g < n_groups; ++g) // (a group whose steps go in one launch: queued whole)
-            if (plans[g].train) {
-                int rc = tiles_launch_train(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin, n_steps);
-                if (rc != REM2D_OK) return rc;
-            }
-        for (int l = 0; l < n_steps; ++l)
+        for (int g = 0; g < n_groups && rcAll == REM2D_OK; ++g) // (a group whose steps go in one launch: queued whole)
+            if (plans[g].train) rcAll = tiles_launch_train(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin, n_steps);
+        for (int l = 0; l < n_steps && rcAll == REM2D_OK; ++l)
             for (int g = 0; g < n_groups; ++g)
                 if (!plans[g].train) tiles_launch_step(plans[g], groups[g].stream ? (hipStream_t)groups[g].stream : origin);
-        HIP_TRY(hipGetLastError());
-    } else {
-        for (int g = 0; g < n_groups; ++g) {
-            int rc = step_fused(groups[g].worlds, groups[g].n_worlds, n_steps, dt, vel_iters, pos_iters,
-                                groups[g].stream ? (hipStream_t)groups[g].stream : origin);
-            if (rc != REM2D_OK) return rc;
+        if (rcAll == REM2D_OK) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rcAll = fail(REM2D_E_HIP, std::string("groups_enqueue: ") + hipGetErrorString(e));
         }
+    } else {
+        for (int g = 0; g < n_groups && rcAll == REM2D_OK; ++g)
+            rcAll = step_fused(groups[g].worlds, groups[g].n_worlds, n_steps, dt, vel_iters, pos_iters,
+                               groups[g].stream ? (hipStream_t)groups[g].stream : origin);
     }
     // join: the origin stream waits for every group
     for (int g = 0; g < n_groups; ++g) {
         hipStream_t sg = groups[g].stream ? (hipStream_t)groups[g].stream : origin;
         if (sg == origin) continue;
         rem2d_world *wg = groups[g].worlds[0];
-        HIP_TRY(hipEventRecord(wg->evJoin, sg));
-        HIP_TRY(hipStreamWaitEvent(origin, wg->evJoin, 0));
+        hipError_t e = hipEventRecord(wg->evJoin, sg);
+        if (e == hipSuccess) e = hipStreamWaitEvent(origin, wg->evJoin, 0);
+        if (e != hipSuccess && rcAll == REM2D_OK) rcAll = fail(REM2D_E_HIP, std::string("groups_enqueue (join): ") + hipGetErrorString(e));
     }
-    return REM2D_OK;
+    return rcAll;
 }
 
 extern "C" int rem2d_groups_step_ex(const rem2d_step_group *groups, int32_t n_groups, int32_t n_steps, float dt,
@@ -1347,6 +1381,14 @@ extern "C" int rem2d_world_debug_words(rem2d_world *w, int32_t *out16) {
     return REM2D_OK;
 }
 #endif
+extern "C" int rem2d_world_handover_failures(const rem2d_world *w, int64_t *count, int32_t clear) {
+    if (!w || !count) return fail(REM2D_E_INVALID, "handover_failures: NULL argument");
+    // (pinned host memory the kernels add to at system scope: readable without a device call; what it holds is what the launches
+    // that have FINISHED so far reported)
+    *count = w->trainFailures ? (int64_t)__atomic_load_n(w->trainFailures, __ATOMIC_RELAXED) : 0;
+    if (clear && w->trainFailures) __atomic_store_n(w->trainFailures, 0u, __ATOMIC_RELAXED);
+    return REM2D_OK;
+}
 extern "C" int rem2d_world_step_time_ms(rem2d_world *w, double *total_ms, int64_t *steps) {
     if (!w) return fail(REM2D_E_INVALID, "world is NULL");
     HIP_TRY(hipSetDevice(w->cfg.device));

@@ -762,10 +762,15 @@ __global__ __launch_bounds__(WAVE * REM2D_VELPOST_WAVES, 4) void rem2d_velpost_k
 //   * No deadlock: the workgroup of a block's previous step has a lower index, so it was dispatched earlier and runs or is done
 //     (the forward-progress assumption of every decoupled look-back scan); every wait is bounded by the clock anyway.
 //   * Hand-over inside an XCD: nPad = the blocks rounded up to a multiple of 8, workgroups go round-robin over the 8 XCDs, so all
-//     steps of a block run on ONE XCD and its state never has to leave that XCD's L2: publishing = the stores have arrived
-//     (s_waitcnt) + a flag, the waiter drops its CU's L1 (buffer_inv sc1).  An agent-scope release (an L2 write-back per item) costs
-//     3 % (profiles/r05_step_train.txt).  The flag carries the publisher's XCC_ID and the waiter compares: a hand-over from another
-//     XCD or a wait that ran into its limit sets REM2D_ERR_HANDOVER on the block's creatures -- never a silent wrong result.
+//     steps of a block run on ONE XCD and its state never has to leave that XCD's L2.  Publisher: an EXPLICIT `s_waitcnt vmcnt(0)`
+//     (the item's stores are acknowledged by the L2), then the flag.  Waiter: the poll, then an EXPLICIT `buffer_inv sc1` +
+//     `s_dcache_inv` (its CU's vector L1 and scalar cache are dropped).  Both are inline assembly, not fences: a workgroup-scope
+//     fence compiles to neither on gfx950, and tools/check_handover_asm.py (run by build() and the CPU tests) reads the two
+//     sequences back from the code object.  An agent-scope release (an L2 write-back per item) costs 3 %
+//     (profiles/r05_step_train.txt).  The flag carries the publisher's XCC_ID and the waiter compares: a hand-over from another
+//     XCD or a wait that ran into its limit sets REM2D_ERR_HANDOVER on the block's creatures and counts into the world's
+//     failure counter in host memory (rem2d_world_handover_failures) -- never a silent wrong result.  The host re-runs such
+//     creatures on per-step launches (evaluate.run_episode).
 //   * Same device functions, same order per creature as the separate launches: same bits (the parity suite runs this launch).
 // A wavefront slot is refilled one block-step at a time and no launch waits for its slowest tile: config 3 1.30 -> 1.02 ms per
 // env-step.  128 VGPRs; the TOI solve (226 VGPRs in its own kernel) spills here (656 spilled VGPRs, all in the post / TOI part: 1 %
@@ -795,9 +800,21 @@ DEV void post_toi_body(const State &S, const Terrain &T, const StepArgs &A, unsi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
-#define TRAIN_FLAG_WORDS 16 // flags[0 .. 16) spare, flags[16 + block] = steps done | publisher's XCC_ID << 16
+#define TRAIN_FLAG_WORDS 16 // flags[0 .. 16) spare (flags[1]: "a wait ran into its limit"), flags[16 + block] = steps done | publisher's XCC_ID << 28
+#define TRAIN_STEP_BITS 28
+#define TRAIN_STEP_MASK ((1u << TRAIN_STEP_BITS) - 1u) // (the host cuts a launch at TRAIN_STEP_MASK steps: rem2d.hip tiles_launch_train)
 #define TRAIN_WAIT_TICKS 200000000ull // 2 s of the 100 MHz clock: a hand-over that never comes must not hang the GPU
-__global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, StepArgs A, Vel4Args V, int *flags, unsigned nBlocks) {
+// REM2D_OPT_TRAIN_FAULT (a test hook, include/rem2d.h): value = s | m << 16 [| 1 << 30]; the items (step s of a launch, block % m == 0):
+// plain -- are told that their hand-over failed; with bit 30 -- their predecessor (step s - 1) does not publish, so they wait
+// into the limit and every later wait of the launch ends at once
+#define TRAIN_FAULT_DROP (1 << 30)
+DEV bool train_fault_hits(int fault, int step, unsigned blk) {
+    const int s = fault & 0xffff;
+    const unsigned m = (unsigned)((fault >> 16) & 0x3fff);
+    return fault != 0 && step == s && (m <= 1u || blk % m == 0u);
+}
+__global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, StepArgs A, Vel4Args V, unsigned *flags, unsigned nBlocks, int fault,
+                                                                    unsigned *failures) {
     __shared__ VelPostShared sh;
     __shared__ ToiSharedT<1> ts1;
     const unsigned nPad = (nBlocks + 7u) & ~7u;
@@ -811,23 +828,27 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
     if (step > 0) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int seen;
-            while (((seen = __hip_atomic_load(&flags[TRAIN_FLAG_WORDS + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff) < step) {
+            unsigned seen;
+            while (((seen = __hip_atomic_load(&flags[TRAIN_FLAG_WORDS + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & TRAIN_STEP_MASK) < (unsigned)step) {
                 __builtin_amdgcn_s_sleep(32);
                 // one wait that ran into the limit ends every later wait of the launch at once (flags[1]): the launch drains in
                 // milliseconds with REM2D_ERR_HANDOVER on what it touched instead of stalling 2 s per item
-                if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+                if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) {
-                    __hip_atomic_store(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bad = 1;
                     break;
                 }
             }
-            if ((unsigned)(seen >> 16) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
+            if ((seen >> TRAIN_STEP_BITS) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
+            if (!(fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step, blk)) bad = 1;
+            // the host learns of it without reading the arena: a counter in pinned host memory (rem2d_world_handover_failures)
+            if (bad) __hip_atomic_fetch_add(failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         bad = __builtin_amdgcn_readfirstlane(bad);
-        // this CU's vector L1 and the scalar data cache (a 64-lane creature's per-creature words are uniform loads) forget what they
-        // hold from an earlier step of the block; the XCD's L2 is current
+        // ACQUIRE, explicit: this CU's vector L1 and the scalar data cache (a 64-lane creature's per-creature words are uniform
+        // loads) forget what they hold from an earlier step of the block; the XCD's L2 is current.  tools/check_handover_asm.py
+        // holds the compiled kernel to this sequence (the poll loop, then buffer_inv sc1 + s_dcache_inv, before any other load).
         asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     unsigned block = blk;
@@ -848,9 +869,14 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     BATCH_DISPATCH(post_toi_body, sh.p, ts1, bad)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (= s_waitcnt: every store of this item has reached the XCD's L2)
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&flags[TRAIN_FLAG_WORDS + blk], (step + 1) | (int)(xcd << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // RELEASE, explicit: a workgroup-scope fence emits NO wait for outstanding stores on gfx950 (the CU's own L1 is coherent for its
+    // own wavefronts, so LLVM needs none) -- but the reader of this flag runs on ANOTHER CU of the XCD.  vmcnt counts stores as well
+    // as loads here (no vscnt before gfx10) and a store leaves the count when the XCD's L2 has acknowledged it: after this wait
+    // every store of the item -- of every lane: one wavefront, one counter -- is in the L2 the next step reads from.  The flag store
+    // must follow with no store of the item's state in between; tools/check_handover_asm.py checks exactly that in the code object.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && !((fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step + 1, blk)))
+        __hip_atomic_store(&flags[TRAIN_FLAG_WORDS + blk], (unsigned)(step + 1) | (xcd << TRAIN_STEP_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #endif

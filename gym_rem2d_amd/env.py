@@ -78,8 +78,13 @@ class BatchedModular2D:
                                 # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
     REBALANCE_EVERY = 50        # env-steps between two re-orderings of a mixed population by current cost (see __init__)
 
-    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False):
+    def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False, options=None, on_handover="raise"):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
+        # options: launch options for every world ({name: value}, _lib.OPTIONS -- launch forms, never results), e.g.
+        # {"fuse_velpost": 1} = per-step launches instead of the step train.  on_handover: what step() / fitness / errors() do when a
+        # step train reported failed hand-overs (rem2d_world_handover_failures): "raise" _lib.HandoverError (nothing computed from
+        # such a state is handed out silently), or "flag" = leave it to the caller, who reads errors() & ERR_HANDOVER
+        # (evaluate.run_episode: re-evaluates those creatures on per-step launches)
         # wide: the worlds live in librem2d_wide.so (32 pair slots / 12 solver slots per body; evaluate.run_episode re-runs
         # there the creatures that overflowed the default build's slots)
         from . import _lib
@@ -113,6 +118,10 @@ class BatchedModular2D:
         # 131 072-creature generation against REM2D_FLAG_RETILE, which it replaces as the policy; +0.5 % on config 4; -0.8 % at
         # 1 M creatures), 0: off.  REM2D_REBALANCE overrides (experiments); rebalance() does the same from the host.
         self.rebalance_every = int(os.environ.get("REM2D_REBALANCE", "-1"))
+        self.options = dict(options or {})
+        if on_handover not in ("raise", "flag"):
+            raise ValueError("on_handover must be 'raise' or 'flag'")
+        self.on_handover = on_handover
 
     def seed(self, seed=None):
         self._seed = seed
@@ -205,7 +214,7 @@ class BatchedModular2D:
         # The step train (the library's default launch form for 64-lane tiles, REM2D_OPT_FUSE_VELPOST = 2: all steps of a call in
         # one launch, block-steps handed from workgroup to workgroup) is ONE in-order train: it wants the whole population in one
         # group (config 3: 64.8 M env-steps/s with one group, 59 M with two, 39 M with four -- profiles/r05_step_train.txt).
-        opts = _lib.env_options()
+        opts = dict(_lib.env_options(), **self.options)
         train = (shape == 3 or (shape is None and _lib.env_tile_shape() == 3)) and not retile and \
             opts.get("fuse_velpost", 2) == 2 and opts.get("pipeline", 3) == 3 and opts.get("debug", 0) == 0
         if train and self.step_groups <= 0:
@@ -237,8 +246,7 @@ class BatchedModular2D:
                     pieces.append((g, mem[lo:lo + per]))
             for g, mem in pieces:
                 part = morph if len(mem) == morph.n_envs else morph.take(mem)
-                w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide,
-                                 options={"rebalance": self._rebalance_steps} if self._rebalance_steps > 0 else None)
+                w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide, options=self._world_options())
                 w.set_terrain(self._terrain())
                 w.reset(part, tile_shape=shape)
                 self.groups[g].append(len(self.worlds))
@@ -261,6 +269,28 @@ class BatchedModular2D:
             for w, idx in self.worlds:
                 w.set_outputs(self._reward, self._done, idx.to(torch.int32))
 
+    def _world_options(self):
+        opts = dict(self.options)
+        if self._rebalance_steps > 0:
+            opts.setdefault("rebalance", self._rebalance_steps)
+        return opts or None
+
+    def handover_failures(self, clear=False):
+        """Failed hand-overs of the step train over all worlds (host-side counters, no synchronisation: what the launches that have
+        finished so far reported)."""
+        return sum(w.handover_failures(clear) for wi, (w, _) in enumerate(self.worlds) if getattr(w, "h", None))
+
+    def check_handover(self, sync=False):
+        """Raise _lib.HandoverError if a step train of this env reported failed hand-overs (unless on_handover == "flag").  sync:
+        wait for the queued launches first -- the counters only know what has finished."""
+        if self.on_handover != "raise" or not self.worlds:
+            return
+        if sync:
+            torch.cuda.synchronize(self.worlds[0][0].device)
+        n = self.handover_failures()
+        if n:
+            raise _lib.HandoverError(n)
+
     def _bind_views(self):
         """Let node.component / robot.components read live poses (host read-back; API parity only)."""
         if self.robots is None:
@@ -282,6 +312,7 @@ class BatchedModular2D:
     def step(self, n_steps=1):
         if not self.groups and len(self.worlds) != 1:   # compact() has retired every world: nothing left to step
             return self._reward, self._done
+        self.check_handover()   # (nothing more is queued behind a launch that reported a failed hand-over)
         if len(self.worlds) == 1:
             self.worlds[0][0].step(n_steps)
         elif (self.merged_launch and len(self.groups) <= _lib.MAX_STEP_GROUPS
@@ -314,6 +345,9 @@ class BatchedModular2D:
                     w.step(n_steps)
             for st in self.streams:
                 cur.wait_stream(st)
+        # (no synchronisation: this sees the launches that have finished -- a failure of the call just queued surfaces at the next
+        # step(), or at fitness / errors(), which wait first)
+        self.check_handover()
         if len(self.worlds) == 1 and not self._compacted:
             w = self.worlds[0][0]
             return w.view("reward"), w.view("done") != 0
@@ -385,8 +419,7 @@ class BatchedModular2D:
                 self._inactive.update(wis)
                 continue
             part = Morphology.concat([self._world_morph[wi].take(k.cpu().numpy()) for wi, k in zip(wis, keeps) if k.numel()])
-            nw = BatchedWorld(n_keep, lanes, self._world_flags, self.device, wide=self.wide,
-                              options={"rebalance": self._rebalance_steps} if self._rebalance_steps > 0 else None)
+            nw = BatchedWorld(n_keep, lanes, self._world_flags, self.device, wide=self.wide, options=self._world_options())
             nw.set_terrain(self._terrain())
             for name in _lib.FIELDS:
                 dst = nw.view(name)
@@ -418,6 +451,7 @@ class BatchedModular2D:
     @property
     def fitness(self):
         """evaluate()'s running fitness (REM2D_main.py:362-377), float64 [N]."""
+        self.check_handover(sync=True)
         return self._gather("fitness", self._fitness)
 
     @property
@@ -430,6 +464,8 @@ class BatchedModular2D:
         return self._gather("steps", self._steps_pop)
 
     def errors(self):
+        """REM2D_ERR_* bits per creature, int32 [N] (the one read that never raises HandoverError: it is how a caller finds the
+        creatures concerned)."""
         return self._gather("err", self._err_pop)
 
     def close(self):

@@ -67,6 +67,8 @@ class SolverOverflow(_lib.Rem2dError):
                          "is not the reference's" % (len(indices), indices[:8], sorted(set(codes))))
 
 
+HandoverError = _lib.HandoverError   # (the step train's hand-over check: a launch-form failure, not a capacity one -- see _lib)
+
 # What a creature gets whose contacts did not fit even the wide build (run_episode's on_error="penalty"): the value
 # evaluate() starts from and returns for an individual that never scored (REM2D_main.py:361 ``fitness = 0``).  Box2D has
 # no contact cap (Modular2DEnv.py:634), the engine here has two tiers (24 / 6, then 32 / 12 pair / solver slots per body);
@@ -77,11 +79,17 @@ UNRESOLVED_FITNESS = 0.0
 
 
 def check_errors(env, on_error="raise"):
-    """Read the per-creature engine error bits of a BatchedModular2D (REM2D_ERR_PAIR_OVERFLOW / _SOLVER_OVERFLOW).
-    on_error: "raise" -> SolverOverflow; "warn" -> warnings.warn and return the mask; "ignore" -> return the mask."""
+    """Read the per-creature engine error bits of a BatchedModular2D.  REM2D_ERR_HANDOVER (the step train's hand-over check) is a
+    launch-form failure and is judged first and apart: "raise" and "warn" both raise HandoverError for it (no mode scores such a
+    creature), "ignore" returns it in the mask.  The capacity bits (REM2D_ERR_PAIR_OVERFLOW / _SOLVER_OVERFLOW) -- on_error:
+    "raise" -> SolverOverflow with the creatures' real codes; "warn" -> warnings.warn and return the mask; "ignore" -> return the
+    mask (every non-zero code)."""
     err = env.errors()
     bad = err != 0
     if on_error != "ignore" and bool(bad.any()):
+        hand = (err & _lib.ERR_HANDOVER) != 0
+        if bool(hand.any()):
+            raise HandoverError(int(hand.sum()), " (creatures, first: %s)" % torch.nonzero(hand).flatten().cpu().tolist()[:8])
         idx = torch.nonzero(bad).flatten().cpu().tolist()
         codes = err[bad].cpu().tolist()
         if on_error == "raise":
@@ -105,43 +113,86 @@ def _episode(env, max_steps, chunk, compact):
             break
 
 
-def reevaluate_wide(env, bad, fit, max_steps=EPISODE_CAP, chunk=100):
-    """The overflow fallback.  Box2D has no cap on the contacts of a body (Modular2DEnv.py:634 world.Step solves whatever
-    touches); the default build keeps 24 pair slots / 6 solver slots per body in HBM / registers and flags the creature
-    that needs more.  Creatures are independent and an episode is a function of the morphology alone, so the flagged ones
-    (``bad``: bool [N] in population order) are simply evaluated again, from reset, in worlds of the wide build
-    (librem2d_wide.so: 32 / 12 slots) -- same kernels, same arithmetic, same bits for everything that fits both.  Writes
-    their fitness into ``fit`` and returns the mask of creatures that overflowed even there."""
+def reevaluate(env, mask, fit, wide=None, options=None, max_steps=EPISODE_CAP, chunk=100):
+    """Creatures are independent and an episode is a function of the morphology alone (fixed terrain seed, open-loop controller:
+    SURVEY facts 5 / 6), so any subset can simply be evaluated AGAIN from reset in worlds of another build or launch form -- same
+    kernels, same arithmetic, same bits for everything both forms can hold.  ``mask``: bool [N] in population order; wide / options:
+    the build (None: the env's own) and launch options of the second run.  Writes the fitness of those creatures into ``fit`` and
+    returns their REM2D_ERR_* codes of the second run as int32 [N] (0 elsewhere).  Two callers:
+      * the overflow fallback (``reevaluate_wide``): Box2D has no cap on the contacts of a body (Modular2DEnv.py:634 world.Step
+        solves whatever touches); the default build keeps 24 pair / 6 solver slots per body and flags the creature that needs
+        more -- re-run in librem2d_wide.so (32 / 12);
+      * the hand-over fallback: creatures a step train flagged REM2D_ERR_HANDOVER -- re-run in the SAME build on per-step launches
+        (``options={"fuse_velpost": 1}``: no hand-over between workgroups exists there)."""
     from .env import BatchedModular2D
-    idx_bad = torch.nonzero(bad).flatten().cpu().numpy()
-    still = torch.zeros_like(bad)
+    idx_bad = torch.nonzero(mask).flatten().cpu().numpy()
+    codes = torch.zeros(mask.shape, dtype=torch.int32, device=mask.device)
     if idx_bad.size == 0:
-        return still
-    wide = BatchedModular2D(hardcore=env.hardcore, flat=env.flat, seed=env._seed, device=env.device, flags=env.flags,
-                            wide=True)
-    wide.terrain = env._terrain()
+        return codes
+    opts = dict(env.options)
+    opts.pop("train_fault", None)   # (a test hook of the first run's launch form; the second run is there to be trusted)
+    opts.update(options or {})
+    again = BatchedModular2D(hardcore=env.hardcore, flat=env.flat, seed=env._seed, device=env.device, flags=env.flags,
+                             wide=env.wide if wide is None else wide, options=opts, on_handover="flag")
+    again.terrain = env._terrain()
     batches = []
     for morph, idx in env._uploaded:
         sel = np.nonzero(np.isin(idx, idx_bad))[0]
         if sel.size:
             batches.append((morph.take(sel), np.searchsorted(idx_bad, idx[sel]).tolist()))
-    wide._upload(batches, int(idx_bad.size))
-    _episode(wide, max_steps, chunk, compact=False)
+    again._upload(batches, int(idx_bad.size))
+    _episode(again, max_steps, chunk, compact=False)
     where = torch.as_tensor(idx_bad, dtype=torch.long, device=fit.device)
-    fit.index_copy_(0, where, wide.fitness.to(fit.device))
-    still.index_copy_(0, where, (wide.errors() != 0).to(still.device))
-    wide.close()
-    return still
+    fit.index_copy_(0, where, again.fitness.to(fit.device))
+    codes.index_copy_(0, where.to(codes.device), again.errors().to(codes.device))
+    again.close()
+    return codes
+
+
+def reevaluate_wide(env, bad, fit, max_steps=EPISODE_CAP, chunk=100):
+    """The overflow fallback (see ``reevaluate``): the creatures of ``bad`` again, from reset, in the wide build.  Writes their
+    fitness into ``fit`` and returns the mask of creatures that overflowed even there."""
+    codes = _resolve_handover(env, reevaluate(env, bad, fit, wide=True, max_steps=max_steps, chunk=chunk), fit, True, max_steps, chunk)
+    return codes != 0
+
+
+def _resolve_handover(env, err, fit, wide, max_steps, chunk):
+    """``err``: REM2D_ERR_* codes [N] of a run in the env's own (wide=None) or the wide build.  The creatures that carry
+    REM2D_ERR_HANDOVER are evaluated again on per-step launches of that build; returns the codes with theirs replaced by the second
+    run's, and logs the event on the env (``env.last_handover``: population indices).  A hand-over bit that survives per-step
+    launches cannot exist (they have no hand-over); if it does, HandoverError."""
+    hand = (err & _lib.ERR_HANDOVER) != 0
+    if not bool(hand.any()):
+        return err
+    idx = torch.nonzero(hand).flatten().cpu().tolist()
+    env.last_handover = sorted(set(getattr(env, "last_handover", [])) | set(idx))
+    import warnings
+    warnings.warn("%d creature(s) were flagged REM2D_ERR_HANDOVER by a step train launch (first: %s): evaluating them again on "
+                  "per-step launches" % (len(idx), idx[:8]))
+    again = reevaluate(env, hand, fit, wide=wide, options={"fuse_velpost": 1}, max_steps=max_steps, chunk=chunk)
+    if bool(((again & _lib.ERR_HANDOVER) != 0).any()):
+        raise HandoverError(int(((again & _lib.ERR_HANDOVER) != 0).sum()), " even on per-step launches")
+    return torch.where(hand, again, err)
 
 
 def run_episode_masked(env, max_steps=EPISODE_CAP, chunk=100, compact=True, fallback=True):
     """run_episode without the verdict: (fitness [N] float64, unresolved [N] bool).  ``unresolved`` marks the creatures
     whose fitness is NOT what the reference's Box2D computes: they overflowed the default build's contact capacity and
     (with ``fallback``) the wide build's as well.  Never raises on overflow -- what a sharded job calls before its
-    collective (a rank that raised here would leave the others waiting in the all-gather)."""
-    _episode(env, max_steps, chunk, compact)
-    fit = env.fitness.clone()
-    bad = check_errors(env, "ignore")
+    collective (a rank that raised here would leave the others waiting in the all-gather).
+    Creatures a step train flagged REM2D_ERR_HANDOVER are ALWAYS resolved here (whatever ``fallback`` says): evaluated again on
+    per-step launches of the same build, never sent to the wide build for it, never penalised; ``env.last_handover`` lists them."""
+    policy, env.on_handover = env.on_handover, "flag"   # (the episode goes on for everybody else; the flagged ones are dealt with below)
+    try:
+        _episode(env, max_steps, chunk, compact)
+        fit = env.fitness.clone()
+        err = env.errors().to(torch.int32)
+    finally:
+        env.on_handover = policy
+    env.last_handover = []
+    if env.handover_failures(clear=True) or bool(((err & _lib.ERR_HANDOVER) != 0).any()):
+        err = _resolve_handover(env, err, fit, None, max_steps, chunk)
+    bad = (err & _lib.ERR_CAPACITY) != 0
     env.last_overflow = torch.nonzero(bad).flatten().cpu().tolist()   # population indices that needed the fallback
     if fallback and bool(bad.any()):
         bad = reevaluate_wide(env, bad, fit, max_steps, chunk)
@@ -184,7 +235,7 @@ def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="fallback", comp
             raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
         return fit
     _episode(env, max_steps, chunk, compact)
-    check_errors(env, on_error)
+    check_errors(env, on_error)   # (REM2D_ERR_HANDOVER raises HandoverError in "raise" and "warn"; so does env.fitness below)
     return env.fitness.clone()
 
 

@@ -191,6 +191,13 @@ class BatchedWorld:
         cols.append(self.view("awake").float())
         return torch.stack(cols, dim=-1).cpu().numpy()
 
+    def handover_failures(self, clear=False):
+        """Hand-overs of this world's step trains that have failed so far (rem2d_world_handover_failures: a word in pinned host
+        memory, no device call, no synchronisation -- what the launches that have FINISHED reported)."""
+        n = C.c_int64()
+        self._check(self.L.rem2d_world_handover_failures(self.h, C.byref(n), 1 if clear else 0))
+        return n.value
+
     def enable_timing(self, on=True):
         """on: False / 0 = off; True = on with room for 4096 timed launches between two read-backs; an int > 1 = on with
         room for that many (the event pairs are created here, two pools of that size)."""

@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define REM2D_ABI_VERSION 10 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
+#define REM2D_ABI_VERSION 11 /* 2: + rem2d_worlds_step(_ex), rem2d_tree_diversity, rem2d_compile_lsystem; 3: + rem2d_world_set_tiles;
                                4: + rem2d_world_set_tile_shape, rem2d_plan_tiles_shape; 5: + rem2d_world_adopt; 6: + rem2d_groups_step(_ex), rem2d_capacity;
                                7: + rem2d_worlds_launch_info; 8: + rem2d_world_set_option / get_option (the library reads no environment variable), rem2d_world_set_order, rem2d_selftest_scalar;
                                9: + rem2d_build_id, rem2d_mutate_trees, count-only compilers (out == NULL); worlds of tile shapes 0 and 2 are refused in one launch;
-                               10: REM2D_OPT_FUSE_VELPOST = 2 (the step train, the new default), REM2D_ERR_HANDOVER, rem2d_worlds_launch_info reports 2 for it */
+                               10: REM2D_OPT_FUSE_VELPOST = 2 (the step train, the new default), REM2D_ERR_HANDOVER, rem2d_worlds_launch_info reports 2 for it;
+                               11: + rem2d_world_handover_failures, REM2D_OPT_TRAIN_FAULT; rem2d_world_step_time_ms counts env-steps, not brackets */
 
 enum {
     REM2D_OK = 0,
@@ -130,7 +131,9 @@ enum { REM2D_DT_F32 = 0, REM2D_DT_I32 = 1, REM2D_DT_F64 = 2 };
 #define REM2D_ERR_PAIR_OVERFLOW 1   /* more than REM2D_CONTACT_SLOTS fat-AABB pairs on a body */
 #define REM2D_ERR_SOLVER_OVERFLOW 2 /* more than REM2D_SOLVER_SLOTS touching contacts on a body */
 #define REM2D_ERR_HANDOVER 4        /* step train (REM2D_OPT_FUSE_VELPOST = 2): a block's previous step was published from another XCD, or a
-                                      wait for it ran into its 2 s limit -- the creature's state is not to be trusted */
+                                      wait for it ran into its 2 s limit -- the creature's state is not to be trusted.  NOT a capacity
+                                      problem: the remedy is the same creature on per-step launches (REM2D_OPT_FUSE_VELPOST = 1) in the
+                                      same build, not the wide build; rem2d_world_handover_failures counts them per world */
 
 int rem2d_abi_version(void);
 /* Identity of this build: the hash of the library's sources (gym_rem2d_amd/csrc/, this header) and compile flags that the
@@ -245,10 +248,16 @@ int rem2d_world_set_order(rem2d_world *w, const int32_t *order_dev, void *stream
  *                             the last step first, a stable partition); 0 (default) off.  Refused with REM2D_FLAG_RETILE.  The step
  *                             train re-orders in front of a launch once N or more steps have run since the last time (a call is
  *                             cut only where it is itself longer than N steps)
+ *   REM2D_OPT_TRAIN_FAULT     test hook of the step train's hand-over check, default 0 = off.  s | m << 16: the workgroups of step s
+ *                             (1-based inside a launch) of the blocks with block % m == 0 (m <= 1: all) are TOLD that their hand-over
+ *                             failed; with bit 30 also set their flag is never published instead, so that they wait into the 2 s
+ *                             limit and every later wait of the launch ends at once.  The arithmetic is untouched; the creatures of
+ *                             those blocks carry REM2D_ERR_HANDOVER and rem2d_world_handover_failures moves
+ *                             (tests/test_handover_gpu.py: the host's re-evaluation on per-step launches gives the oracle's fitness)
  * Returns REM2D_E_INVALID for an unknown key or a value outside the option's range. */
 enum {
     REM2D_OPT_PIPELINE = 0, REM2D_OPT_FUSE_VELPOST, REM2D_OPT_PRIO, REM2D_OPT_PRIO_T1, REM2D_OPT_PRIO_T2,
-    REM2D_OPT_HEAVY_PER_WAVE, REM2D_OPT_DEBUG, REM2D_OPT_REBALANCE, REM2D_OPT_COUNT
+    REM2D_OPT_HEAVY_PER_WAVE, REM2D_OPT_DEBUG, REM2D_OPT_REBALANCE, REM2D_OPT_TRAIN_FAULT, REM2D_OPT_COUNT
 };
 int rem2d_world_set_option(rem2d_world *w, int32_t key, int32_t value);
 int rem2d_world_get_option(const rem2d_world *w, int32_t key, int32_t *value);
@@ -411,8 +420,15 @@ int rem2d_world_field(const rem2d_world *w, int32_t field, size_t *offset_bytes,
  * with HIP events on the launch stream (bench.py's roofline leg).  Synchronises. */
 int rem2d_world_kernel_time_ms(rem2d_world *w, double *total_ms, int64_t *launches);
 /* The same for the whole kernel sequence of one env-step (pre, velocity, post, TOI scan, TOI solve) of the tile pipeline:
- * device time between the first kernel's start and the last kernel's end, summed over the steps since the last call. */
+ * device time between the first kernel's start and the last kernel's end, summed over the steps since the last call.
+ * `steps` counts ENV-STEPS: a step train's bracket spans a whole launch and adds the steps of that launch. */
 int rem2d_world_step_time_ms(rem2d_world *w, double *total_ms, int64_t *steps);
+/* How many hand-overs of this world's step trains have failed so far (REM2D_ERR_HANDOVER: the count of (step, block) workgroups,
+ * booked on the FIRST world of a launch / step group): read from a word in pinned host memory that the kernels add to, so the call
+ * neither synchronises nor touches the device; it reports what the launches that have finished so far saw.  clear != 0 resets it.
+ * (b2World::Step cannot fail this way: Modular2DEnv.py:634 is one synchronous call.  A host checks this after a step call and
+ * before trusting reward / done -- gym_rem2d_amd.env.BatchedModular2D.step raises HandoverError.) */
+int rem2d_world_handover_failures(const rem2d_world *w, int64_t *count, int32_t clear);
 /* on = 0: off; on = 1: on, room for 4096 timed launches between two read-backs; on > 1: room for `on` launches.  The
  * event pairs are created here, not inside the step calls. */
 int rem2d_world_enable_timing(rem2d_world *w, int32_t on);

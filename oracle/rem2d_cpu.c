@@ -122,7 +122,7 @@ int rem2d_cpu_world_create(const rem2d_world_cfg *cfg, void *state_host, size_t 
     w->slotBody = (int8_t *)malloc((size_t)cfg->n_envs * cfg->lanes);
     if (!w->worlds || !w->slotBody) { free(w->worlds); free(w->slotBody); free(w); return c_fail(REM2D_E_NOMEM, "out of memory"); }
     memset(w->arena, 0, L.total);
-    { static const int32_t def[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0, 0}; memcpy(w->opt, def, sizeof def); }
+    { static const int32_t def[REM2D_OPT_COUNT] = {3, 1, 5, 60, 75, 1, 0, 0, 0}; memcpy(w->opt, def, sizeof def); }
     *out = w;
     return REM2D_OK;
 }
@@ -179,7 +179,7 @@ int rem2d_cpu_world_set_order(rem2d_cpu_world *w, const int32_t *order, void *st
 }
 /* launch options (include/rem2d.h REM2D_OPT_*): kept and handed back, nothing to steer on the CPU; same range checks */
 int rem2d_cpu_world_set_option(rem2d_cpu_world *w, int32_t key, int32_t value) {
-    static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30, 1 << 20};
+    static const int32_t lo[REM2D_OPT_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0, 0}, hi[REM2D_OPT_COUNT] = {3, 1, 7, 1 << 20, 1 << 20, 64, 1 << 30, 1 << 20, 0x7fffffff};
     if (!w) return c_fail(REM2D_E_INVALID, "world is NULL");
     if (key < 0 || key >= REM2D_OPT_COUNT) return c_fail(REM2D_E_INVALID, "set_option: unknown option");
     if (value < lo[key] || value > hi[key] || (key == REM2D_OPT_PIPELINE && value != 0 && value != 3))
@@ -408,6 +408,13 @@ int rem2d_cpu_world_kernel_time_ms(rem2d_cpu_world *w, double *total_ms, int64_t
     if (total_ms) *total_ms = 0.0;
     if (launches) *launches = 0;
     return w ? REM2D_OK : c_fail(REM2D_E_INVALID, "world is NULL");
+}
+/* (no launches on the host, so no hand-over between them: always 0) */
+int rem2d_cpu_world_handover_failures(const rem2d_cpu_world *w, int64_t *count, int32_t clear) {
+    (void)clear;
+    if (!w || !count) return c_fail(REM2D_E_INVALID, "handover_failures: NULL argument");
+    *count = 0;
+    return REM2D_OK;
 }
 int rem2d_cpu_world_step_time_ms(rem2d_cpu_world *w, double *total_ms, int64_t *steps) {
     if (total_ms) *total_ms = 0.0;

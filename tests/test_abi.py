@@ -45,7 +45,7 @@ def test_error_bits_match_header(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.rem2d_abi_version() == 10
+    assert L.rem2d_abi_version() == 11
     assert lib.capacity() == (lib.CONTACT_SLOTS, lib.SOLVER_SLOTS) == (24, 6) and lib.capacity(wide=True) == (32, 12)
     # a wide world's arena is laid out for its own slot count
     big = lib.WorldCfg(4096, 8, 0, 0)
@@ -125,5 +125,38 @@ def test_build_identity(lib, tmp_path, monkeypatch):
         lib.lib()
     # an experiment's variant build named through REM2D_LIB_PATH is exempt (tools/build_variant.sh)
     monkeypatch.setenv("REM2D_LIB_PATH", lib.LIB_PATH)
-    assert lib.lib().rem2d_abi_version() == 10
+    assert lib.lib().rem2d_abi_version() == 11
     monkeypatch.setattr(lib, "_lib", None)
+
+
+def test_step_train_handover_sequences_in_the_code_objects(lib):
+    """The step train's hand-over as COMPILED (tools/check_handover_asm.py; VERDICT r5 weak 2: the publish was ordered by the
+    accident of a register spill).  In every build: walking back from the flag store every path meets `s_waitcnt vmcnt(0)` before
+    any store to memory; after a poll of the flag every path meets buffer_inv sc1 + s_dcache_inv before any other load.  And the
+    checker itself notices when they are missing: the same disassembly with the waits / the invalidate taken out is refused."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_handover_asm as H
+    import tempfile
+    for path in (lib.LIB_PATH, lib.WIDE_LIB_PATH, lib.FMA_LIB_PATH):
+        rep = H.check_library(path)
+        assert len(rep) >= 1
+        for sym, r in rep.items():
+            assert r["polls"] >= 1 and r["publish_waitcnt"] and r["resources"]["vgprs"] <= 128, (path, sym, r)
+    # negative controls on the default build's kernel(s)
+    with tempfile.TemporaryDirectory() as wd:
+        co = H.code_object(lib.LIB_PATH, wd)
+        for sym in H.train_symbols(co):
+            ins = H.disassemble(co, sym)
+            H.check_kernel(ins, sym)
+            nop = lambda i: (i[0], "s_nop", "0", None)
+            no_wait = [nop(i) if (i[1] == "s_waitcnt" and "vmcnt(0)" in i[2]) else i for i in ins]
+            with pytest.raises(H.HandoverAsmError, match="s_waitcnt vmcnt|flag store"):
+                H.check_kernel(no_wait, sym)
+            no_inv = [nop(i) if i[1] in ("buffer_inv", "s_dcache_inv") else i for i in ins]
+            with pytest.raises(H.HandoverAsmError):
+                H.check_kernel(no_inv, sym)
+            # only the scalar-cache invalidate missing (round 5's late fix b600711): refused as well
+            no_dc = [nop(i) if i[1] == "s_dcache_inv" else i for i in ins]
+            with pytest.raises(H.HandoverAsmError, match="s_dcache_inv"):
+                H.check_kernel(no_dc, sym)
