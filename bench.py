@@ -316,6 +316,97 @@ def cpu_baseline(morphs, terrain, flags, settle, window, budget_s=20.0):
                       % (n, lanes, settle, settle + window, tw, cores, n1, w1)}
 
 
+def _reference_worker(job):
+    """One worker of reference_baseline (a forked process, like a worker of the reference's multiprocessing pool): the reference's
+    own env over real Box2D for a slice of config 3's seeds -- reset, `settle` untimed steps, `window` timed steps per creature."""
+    reference, seeds, settle, window = job
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import capture_golden as cg
+    cg.REF = reference
+    if reference not in sys.path:
+        sys.path.insert(0, reference)
+    try:
+        import gym  # noqa: F401
+    except ImportError:
+        cg.install_gym_stub()
+    try:
+        import neat  # noqa: F401
+    except ImportError:
+        cg.install_neat_stub()
+    import matplotlib
+    matplotlib.use("Agg")
+    cg.alias_case_insensitive()
+    from Encodings import lsystem as ls
+    from gym_rem2D.morph import simple_module, circular_module
+    from gym_rem2D.envs import Modular2DEnv as M
+    M.MAX_PERTURBANCE_TERRAIN = 0   # config 3: flat terrain
+    steps, spent = 0, 0.0
+    env = M.Modular2D()
+    for seed in seeds:
+        random.seed(int(seed))
+        ml = [simple_module.Standard2D() for _ in range(4)] + [circular_module.Circular2D() for _ in range(4)]
+        g = ls.LSystem(ml)
+        g.maxModules = 15
+        tree = g.create(8)
+        env.seed(4)
+        env.reset(tree=tree, module_list=ml)     # REM2D_main.py:357-359
+        action = np.ones(4)
+        for _ in range(settle):
+            env.step(action)
+        t0 = time.perf_counter()
+        for _ in range(window):                  # REM2D_main.py:362-368: the body of evaluate()'s loop, no early exit (SURVEY 8d)
+            env.step(action)
+        spent += time.perf_counter() - t0
+        steps += window
+    return steps, spent
+
+
+def reference_baseline(settle, window, budget_s=20.0):
+    """SURVEY 8d's timing plan: `try: import Box2D` -> the REFERENCE's own Modular2D.step over the real engine, one env per host core
+    the way REM2D_main.py:256-267's pool.map runs evaluate() (:350-378), on the first creatures of config 3.  Needs the wheel
+    (requirements.txt:1 of the reference: Box2D==2.3.10) AND a checkout of the reference named by REM2D_REFERENCE (nothing is
+    read from /root/reference by default: it does not exist on the GPU box).  Returns None when either is missing -- which is the
+    case in this image and on the GPU box, so `cpu_baseline.kind` is "port" there."""
+    try:
+        import Box2D  # noqa: F401
+    except ImportError:
+        return None
+    reference = os.environ.get("REM2D_REFERENCE", "")
+    if not reference or not os.path.isdir(os.path.join(reference, "gym_rem2D")):
+        return None
+    import multiprocessing as mp
+    cores, quota = host_cores()
+    # size: one creature first (its rate sizes the sample to the budget)
+    n1, t1 = _reference_worker((reference, [0, 1], settle, min(window, 50)))
+    rate1 = n1 / max(t1, 1e-6)
+    per_core = max(2, min(64, int(budget_s * rate1 / (settle + window))))
+    jobs = [(reference, list(range(c * per_core, (c + 1) * per_core)), settle, window) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        parts = pool.map(_reference_worker, jobs)
+    wall = time.perf_counter() - t0
+    steps = sum(p[0] for p in parts)
+    busy = max(p[1] for p in parts)          # the timed windows run side by side: the slowest worker's is the wall time of the window
+    import Box2D as B
+    return {"value": steps / max(busy, 1e-6), "unit": "env-steps/s", "cores": cores, "kind": "reference", "is_oracle": False,
+            "cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota,
+            "what": "the reference's own gym_rem2D.envs.Modular2DEnv.Modular2D.step over pybox2d %s, one env per worker process "
+                    "(REM2D_main.py:256-267 pool.map)" % getattr(B, "__version__", "?"),
+            "value_1thread": rate1,
+            "sample": "%d creatures (config 3's seeds 0..%d, %d per worker), steps [%d, %d) after reset timed per creature, %d "
+                      "worker processes; pool wall time incl. resets and settle steps %.1f s"
+                      % (cores * per_core, cores * per_core - 1, per_core, settle, settle + window, cores, wall)}
+
+
+# Context for the baseline (SURVEY.md 6 / Appendix D, measured by the survey in the build container with a recording world in
+# place of Box2D): what the reference's step() costs in Python alone, before any physics.
+REFERENCE_PYTHON_OVERHEAD = {"step_us_color_control_on": 2287, "step_us_color_control_off": 8, "reset_ms": 2.9,
+                             "source": "SURVEY.md 6 (Modular2DEnv.py:624-628 COLOR_CONTROL = a matplotlib colour-map lookup per "
+                                       "node and step; stub world.Step, 8-module L-system creature, one core) -- Python only, "
+                                       "Box2D not included"}
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` without a launcher around it: start N ranks with torch.distributed.run as a CHILD process
     (this parent has not touched the GPU -- no torch import, no HIP call -- and never execs) and relay its output.
@@ -720,8 +811,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from gym_rem2d_amd import make_terrain as _mt
             window = args.steps if not generation else 200
-            out["cpu_baseline"] = cpu_baseline(morphs, _mt(4, flat=flat, hardcore=hard), 0 if args.discrete else 1,
-                                               args.settle + args.warmup, window)
+            # the real reference if the wheel and a checkout are there (kind "reference"), else the port
+            ref = reference_baseline(args.settle + args.warmup, int(max(100, min(window, 400)))) \
+                if (args.workload == "lsystem" and not args.discrete) else None
+            out["cpu_baseline"] = ref if ref is not None else \
+                cpu_baseline(morphs, _mt(4, flat=flat, hardcore=hard), 0 if args.discrete else 1, args.settle + args.warmup, window)
+            out["cpu_baseline"]["reference_python_overhead"] = REFERENCE_PYTHON_OVERHEAD
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

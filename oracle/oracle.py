@@ -84,6 +84,12 @@ def _load(path):
         L.rem2d_oracle_set_motor_speed.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.rem2d_oracle_set_velocity.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 3
         L.rem2d_oracle_set_gravity.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.rem2d_oracle_set_body_state.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 6 + [C.c_int]
+        L.rem2d_oracle_set_joint_impulses.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4
+        L.rem2d_oracle_set_contact_impulses.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 4
+        L.rem2d_oracle_get_wod.restype = C.c_double
+        L.rem2d_oracle_get_wod.argtypes = [C.c_void_p]
+        L.rem2d_oracle_get_controller_state.argtypes = [C.c_void_p, C.c_void_p]
         L.rem2d_oracle_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int]
         L.rem2d_oracle_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rem2d_oracle_env_step_ex.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -191,6 +197,25 @@ class World:
 
     def set_gravity(self, gx, gy):
         lib().rem2d_oracle_set_gravity(self.h, gx, gy)
+
+    # ---- state re-synchronisation (tests/test_box2d_pin.py): exactly what pybox2d lets a script read from a b2World ----
+    def set_body_state(self, body, x, y, angle, vx, vy, w, awake=1):
+        lib().rem2d_oracle_set_body_state(self.h, body, x, y, angle, vx, vy, w, int(awake))
+
+    def set_joint_impulses(self, joint, ix, iy, iz, motor_impulse):
+        lib().rem2d_oracle_set_joint_impulses(self.h, joint, ix, iy, iz, motor_impulse)
+
+    def set_contact_impulses(self, body, k, n0, n1, t0, t1):
+        lib().rem2d_oracle_set_contact_impulses(self.h, body, k, n0, n1, t0, t1)
+
+    @property
+    def wod(self):
+        return lib().rem2d_oracle_get_wod(self.h)
+
+    def controller_state(self):
+        out = np.zeros(max(1, self.n_joints), dtype=np.float64)
+        lib().rem2d_oracle_get_controller_state(self.h, _ptr(out))
+        return out[:self.n_joints].copy()
 
     def step(self, dt=1.0 / 50, vel_iters=180, pos_iters=60):
         lib().rem2d_oracle_world_step(self.h, dt, vel_iters, pos_iters)

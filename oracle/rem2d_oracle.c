@@ -658,6 +658,50 @@ void rem2d_oracle_set_velocity(o_world *w, int body, float vx, float vy, float w
     b->w = wz;
 }
 
+/* ---- state re-synchronisation (tests/test_box2d_pin.py: SURVEY 8c protocol (i), "identical full state in, one step out") ----
+ * Setters for exactly the state pybox2d lets a script READ from a b2World (body pose / velocity / awake flag, the revolute joint's
+ * accumulated impulses, a manifold's warm-start impulses): the pin test runs this oracle beside a recorded trajectory of the real
+ * engine and, before every step, overwrites these floats with the recording's so that differences cannot accumulate across
+ * steps.  What pybox2d does not expose (sleep timers, fat AABBs, limit states, the contact lists' order) stays the oracle's own.
+ * No arithmetic of the step reads anything these functions compute except b2Rot::Set of the angle, which b2Body::SetTransform
+ * does the same way.  Test infrastructure like the rest of this file. */
+void rem2d_oracle_set_body_state(o_world *w, int body, float x, float y, float angle, float vx, float vy, float wz, int awake) {
+    body_t *b = &w->bodies[body];
+    /* b2Body::SetTransform: xf, then sweep.c = xf * localCenter, a, c0 = c, a0 = a (fixtures' proxies are NOT re-synchronised
+     * here: the fat AABB is the oracle's own, see above) */
+    b->xf.q = rot_set(angle);
+    b->xf.p = V2(x, y);
+    b->c = xmul(b->xf, b->localCenter);
+    b->a = angle;
+    b->c0 = b->c;
+    b->a0 = angle;
+    b->v = V2(vx, vy);
+    b->w = wz;
+    b->awake = awake ? 1 : 0;
+}
+void rem2d_oracle_set_joint_impulses(o_world *w, int joint, float ix, float iy, float iz, float motorImpulse) {
+    joint_t *j = &w->joints[joint];
+    j->impulse.x = ix;
+    j->impulse.y = iy;
+    j->impulse.z = iz;
+    j->motorImpulse = motorImpulse;
+}
+/* contact k of the body's list (rem2d_oracle_get_contacts order) */
+void rem2d_oracle_set_contact_impulses(o_world *w, int body, int k, float n0, float n1, float t0, float t1) {
+    body_t *b = &w->bodies[body];
+    if (k < 0 || k >= b->ncontacts) return;
+    contact_t *c = &w->contacts[b->contacts[k]];
+    c->m.points[0].normalImpulse = n0;
+    c->m.points[1].normalImpulse = n1;
+    c->m.points[0].tangentImpulse = t0;
+    c->m.points[1].tangentImpulse = t1;
+}
+double rem2d_oracle_get_wod(const o_world *w) { return w->wod; }
+/* out[njoint] = the controllers' i_state (Controller/m_controller.py:17-21) */
+void rem2d_oracle_get_controller_state(const o_world *w, double *out) {
+    for (int i = 0; i < w->njoint; ++i) out[i] = w->joints[i].istate;
+}
+
 /* ---- A.7 narrowphase ---- */
 static void collide_edge_circle(manifold_t *m, const shape_t *edgeA, xf_t xfA, const shape_t *circleB,
                                 xf_t xfB) {

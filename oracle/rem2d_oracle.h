@@ -69,6 +69,12 @@ void rem2d_oracle_set_controller(o_world *, int joint, double amp, double phase,
 void rem2d_oracle_set_motor_speed(o_world *, int joint, float speed);
 void rem2d_oracle_set_velocity(o_world *, int body, float vx, float vy, float w);
 void rem2d_oracle_set_gravity(o_world *, float gx, float gy);
+/* state re-synchronisation for tests/test_box2d_pin.py (what pybox2d exposes of a b2World, see rem2d_oracle.c) */
+void rem2d_oracle_set_body_state(o_world *, int body, float x, float y, float angle, float vx, float vy, float w, int awake);
+void rem2d_oracle_set_joint_impulses(o_world *, int joint, float ix, float iy, float iz, float motorImpulse);
+void rem2d_oracle_set_contact_impulses(o_world *, int body, int k, float n0, float n1, float t0, float t1);
+double rem2d_oracle_get_wod(const o_world *);
+void rem2d_oracle_get_controller_state(const o_world *, double *out);
 /* b2World::Step */
 void rem2d_oracle_world_step(o_world *, float dt, int velIters, int posIters);
 /* Modular2D.step (Modular2DEnv.py:607-653): wod, controllers, PID, Step(1/50,180,60), reward/done */

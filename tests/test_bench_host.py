@@ -130,3 +130,25 @@ def test_cpu_baseline_sample_is_capped_by_host_memory(monkeypatch, oracle):
     cb = bench.cpu_baseline([m], make_terrain(4, flat=True), 1, settle=5, window=20, budget_s=2.0)
     n = int(cb["sample"].split(" creatures")[0])
     assert 32 <= n <= 70, cb["sample"]
+
+
+def test_reference_baseline_leg_is_dormant_without_the_wheel(monkeypatch):
+    """`try: import Box2D` -> the reference's own step loop as `cpu_baseline.kind = "reference"`; else the port.  The wheel
+    (Box2D==2.3.10, the reference's requirements.txt:1) is on neither box: the leg answers None and never looks for a checkout --
+    and even WITH the wheel it reads a reference checkout only where REM2D_REFERENCE names one (never /root/reference by default:
+    that path does not exist on the GPU box)."""
+    import bench
+    try:
+        import Box2D  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    monkeypatch.delenv("REM2D_REFERENCE", raising=False)
+    assert bench.reference_baseline(25, 100) is None
+    if not have:
+        monkeypatch.setenv("REM2D_REFERENCE", "/root/reference/ModularER_2D")
+        assert bench.reference_baseline(25, 100) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "/root/reference" not in src.split("def reference_baseline")[1].split("\ndef ")[0].replace(
+        "nothing is\n    read from /root/reference by default", "")
+    assert bench.REFERENCE_PYTHON_OVERHEAD["step_us_color_control_on"] == 2287
