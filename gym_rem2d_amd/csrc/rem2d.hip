@@ -441,11 +441,11 @@ extern "C" int rem2d_world_set_tiles(rem2d_world *w, const int32_t *tile_start, 
     w->tilesDev = dev;
     w->nTiles = n_tiles;
     w->S.tiles = dev;
-    // a regular table (tile t = creatures [t cap, (t + 1) cap), cap dividing the creatures of a 64-lane block): the
-    // velocity + position launch can find the tiles of a block
+    // a regular table (tile t = creatures [t cap, (t + 1) cap), cap dividing the creatures of a 64-lane block -- or a multiple of
+    // them: a tile of whole blocks): the velocity + position launch and the step trains can find the tiles of a block
     {
         const int cap = tile_start[1] - tile_start[0], cpb = WAVE / w->cfg.lanes;
-        bool regular = w->cfg.lanes <= WAVE && cap > 0 && cpb % cap == 0 && tile_start[n_tiles] <= n_tiles * cap;
+        bool regular = w->cfg.lanes <= WAVE && cap > 0 && (cpb % cap == 0 || cap % cpb == 0) && tile_start[n_tiles] <= n_tiles * cap;
         for (int t = 0; t < n_tiles && regular; ++t) regular = tile_start[t] == t * cap;
         w->S.nTiles = n_tiles;
         w->S.tileCap = regular ? cap : 0;
@@ -756,6 +756,8 @@ struct TilePlan {
     bool continuous;
     bool velpost; // one launch for the velocity iterations and post (rem2d_velpost_kernel)
     bool train;   // ... and ONE launch for all steps of a call, pre and the TOI solve included (rem2d_step_train_kernel; REM2D_OPT_FUSE_VELPOST = 2)
+    bool train128; // ... the same for the 128-lane tile shapes 1 / 4 (rem2d_step_train128_kernel: an item = a tile's one or two blocks)
+    unsigned items; // items per step of that launch: blocks (64-lane train) / tile-sized groups of blocks summed over the worlds (128-lane)
     rem2d_world *w0;
     rem2d_world *ws[REM2D_MAX_BATCH]; // the group's worlds (REM2D_OPT_REBALANCE runs per world)
     int nw;
@@ -801,12 +803,28 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
         if (tile_shape_rank(id) > tile_shape_rank(P.launchShape)) P.launchShape = id;
     }
     P.velpost = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] != 0 && P.launchShape == 3;
-    for (int i = 0; i < n_worlds; ++i)
-        P.velpost = P.velpost && ws[i]->S.tileCap > 0 && ws[i]->tileShape == 3; // (REM2D_FLAG_RETILE: tile slots and block slots go through the same creature order)
+    for (int i = 0; i < n_worlds; ++i) // (a tile within a block: cap <= the creatures of a block)
+        P.velpost = P.velpost && ws[i]->S.tileCap > 0 && ws[i]->S.tileCap * ws[i]->cfg.lanes <= WAVE && ws[i]->tileShape == 3; // (REM2D_FLAG_RETILE: tile slots and block slots go through the same creature order)
     // the step train: where the one-launch form is possible, for worlds whose creature order does not change inside a launch
     // (REM2D_FLAG_RETILE re-deals it in every step, grid-wide) and outside the fused kernel's diagnostics (REM2D_OPT_DEBUG)
-    P.train = P.velpost && ws[0]->opt[REM2D_OPT_FUSE_VELPOST] == 2 && ws[0]->opt[REM2D_OPT_DEBUG] == 0;
+    const bool wantTrain = ws[0]->opt[REM2D_OPT_FUSE_VELPOST] == 2 && ws[0]->opt[REM2D_OPT_DEBUG] == 0;
+    P.train = P.velpost && wantTrain;
     for (int i = 0; i < n_worlds; ++i) P.train = P.train && !(ws[i]->cfg.flags & REM2D_FLAG_RETILE);
+    P.items = blocks;
+    // ... and its form for the 128-lane tile shapes (1 flexible, 4 static): regular tables of tiles of at most two blocks
+    P.train128 = !P.train && wantTrain && (P.launchShape == 1 || P.launchShape == 4);
+    if (P.train128) {
+        unsigned items = 0;
+        for (int i = 0; i < n_worlds; ++i) {
+            const rem2d_world *w = ws[i];
+            P.train128 = P.train128 && !(w->cfg.flags & REM2D_FLAG_RETILE) && w->S.tileCap > 0 && w->S.tileCap * w->cfg.lanes <= 2 * WAVE &&
+                         (w->tileShape == 3 || w->tileShape == 1 || w->tileShape == 4);
+            const unsigned lanesPerTile = (unsigned)w->S.tileCap * (unsigned)w->cfg.lanes, bpt = lanesPerTile > WAVE ? lanesPerTile / WAVE : 1u;
+            items += ((unsigned)w->L.Lp / WAVE + bpt - 1) / bpt; // (the kernel's item -> world walk does the same sum)
+        }
+        if (P.train128) P.items = items;
+    }
+    P.train = P.train || P.train128;
     P.continuous = (ws[0]->cfg.flags & REM2D_FLAG_CONTINUOUS) != 0;
     P.A.nSteps = 1;
     P.A.dt = dt;
@@ -901,7 +919,7 @@ static void tiles_launch_step(const TilePlan &P, hipStream_t st) {
 // the old buffer, which waits for the launches that use it)
 static int train_reserve(TilePlan &P) {
     rem2d_world *w0 = P.w0;
-    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.blocks;
+    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.items;
     if (w0->trainCap < need) {
         if (w0->trainFlags) HIP_TRY(hipFree(w0->trainFlags));
         w0->trainFlags = nullptr; w0->trainCap = 0;
@@ -916,9 +934,9 @@ static int train_reserve(TilePlan &P) {
 }
 static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
     rem2d_world *w0 = P.w0;
-    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.blocks;
+    const size_t need = TRAIN_FLAG_WORDS + (size_t)P.items;
     { int rc = train_reserve(P); if (rc != REM2D_OK) return rc; }
-    const unsigned nPad = (P.blocks + 7u) & ~7u;
+    const unsigned nPad = (P.items + 7u) & ~7u;
     const int fault = w0->opt[REM2D_OPT_TRAIN_FAULT];
     // The creature order is re-made in front of a launch once N (REM2D_OPT_REBALANCE) or more steps have run since the last time --
     // a cadence in launches, not in steps: a call is cut only where it is itself longer than N steps, never because a multiple
@@ -948,13 +966,18 @@ static int tiles_launch_train(TilePlan &P, hipStream_t st, int n_steps) {
         HIP_TRY(hipMemsetAsync(w0->trainFlags, 0, need * sizeof(unsigned), st));
         P.A.nSteps = seg;
         const dim3 grid(nPad * (unsigned)seg), block(WAVE);
-        if (w0->timing && w0->evUsed < (int)w0->evPool.size()) {
-            hipExtLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, w0->evPool[w0->evUsed].first, w0->evPool[w0->evUsed].second, 0,
-                                  P.B, P.A, P.V, w0->trainFlags, P.blocks, fault, w0->trainFailures);
-            w0->evUsed += 1;
-        } else {
-            hipLaunchKernelGGL(rem2d_step_train_kernel, grid, block, 0, st, P.B, P.A, P.V, w0->trainFlags, P.blocks, fault, w0->trainFailures);
-        }
+        const bool timed = w0->timing && w0->evUsed < (int)w0->evPool.size();
+        hipEvent_t e0 = timed ? w0->evPool[w0->evUsed].first : nullptr, e1 = timed ? w0->evPool[w0->evUsed].second : nullptr;
+#define TRAIN_LAUNCH(KERNEL)                                                                                                              \
+        do {                                                                                                                              \
+            if (timed) hipExtLaunchKernelGGL(KERNEL, grid, block, 0, st, e0, e1, 0, P.B, P.A, P.V, w0->trainFlags, P.items, fault, w0->trainFailures); \
+            else hipLaunchKernelGGL(KERNEL, grid, block, 0, st, P.B, P.A, P.V, w0->trainFlags, P.items, fault, w0->trainFailures);          \
+        } while (0)
+        if (!P.train128) TRAIN_LAUNCH(rem2d_step_train_kernel);
+        else if (P.launchShape == 4) TRAIN_LAUNCH((rem2d_step_train128_kernel<false, REM2D_SHAPE4_WPS>));
+        else TRAIN_LAUNCH((rem2d_step_train128_kernel<true, REM2D_SHAPE1_WPS>));
+#undef TRAIN_LAUNCH
+        if (timed) w0->evUsed += 1;
         if (timedStep) {
             (void)hipEventRecord(w0->evPoolStep[w0->evUsedStep].second, st);
             if (w0->evStepCount.size() < w0->evPoolStep.size()) w0->evStepCount.resize(w0->evPoolStep.size(), 1);
@@ -1031,7 +1054,7 @@ extern "C" int rem2d_worlds_launch_info(rem2d_world *const *ws, int32_t n_worlds
     SHAPES_TRY(ws, n_worlds);
     tiles_plan(P, ws, n_worlds, 1.0f / 50.0f, 180, 60);
     if (tile_shape_out) *tile_shape_out = P.launchShape;
-    if (fused_velpost) *fused_velpost = P.train ? 2 : (P.velpost ? 1 : 0);
+    if (fused_velpost) *fused_velpost = P.train ? 2 : (P.velpost ? 1 : 0); // (2 with tile shape 1 / 4: rem2d_step_train128_kernel)
     return REM2D_OK;
 }
 

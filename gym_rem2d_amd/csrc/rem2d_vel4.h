@@ -813,6 +813,50 @@ DEV bool train_fault_hits(int fault, int step, unsigned blk) {
     const unsigned m = (unsigned)((fault >> 16) & 0x3fff);
     return fault != 0 && step == s && (m <= 1u || blk % m == 0u);
 }
+// The waiter's half of a hand-over: lane 0 polls the item's flag until step `step` of the item is published (or the clock / another
+// wait's verdict ends the wait), compares the publisher's XCD, books a failure; then the EXPLICIT acquire for the whole wavefront.
+// Returns `bad` (uniform).  `fl`: index of the item's flag word; `blk`: what REM2D_OPT_TRAIN_FAULT's modulus counts.
+DEV int train_acquire(unsigned *flags, unsigned fl, int step, unsigned xcd, int fault, unsigned blk, unsigned *failures) {
+    int bad = 0;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned seen;
+        while (((seen = __hip_atomic_load(&flags[fl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & TRAIN_STEP_MASK) < (unsigned)step) {
+            __builtin_amdgcn_s_sleep(32);
+            // one wait that ran into the limit ends every later wait of the launch at once (flags[1]): the launch drains in
+            // milliseconds with REM2D_ERR_HANDOVER on what it touched instead of stalling 2 s per item
+            if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) {
+                __hip_atomic_store(&flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
+                break;
+            }
+        }
+        if ((seen >> TRAIN_STEP_BITS) != xcd) bad = 1; // the item's previous step ran on another XCD: its stores may still sit in that L2
+        if (!(fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step, blk)) bad = 1;
+        // the host learns of it without reading the arena: a counter in pinned host memory (rem2d_world_handover_failures)
+        if (bad) __hip_atomic_fetch_add(failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bad = __builtin_amdgcn_readfirstlane(bad);
+    // ACQUIRE, explicit: this CU's vector L1 and the scalar data cache (a 64-lane creature's per-creature words are uniform
+    // loads) forget what they hold from an earlier step of the item; the XCD's L2 is current.  tools/check_handover_asm.py
+    // holds the compiled kernels to this sequence (the poll loop, then buffer_inv sc1 + s_dcache_inv, before any other load).
+    asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    return bad;
+}
+// The publisher's half.  RELEASE, explicit: a workgroup-scope fence emits NO wait for outstanding stores on gfx950 (the CU's own L1
+// is coherent for its own wavefronts, so LLVM needs none) -- but the reader of this flag runs on ANOTHER CU of the XCD.  vmcnt
+// counts stores as well as loads here (no vscnt before gfx10) and a store leaves the count when the XCD's L2 has acknowledged it:
+// after this wait every store of the item -- of every lane: one wavefront, one counter -- is in the L2 the next step reads from.
+// The flag store must follow with no store of the item's state in between; tools/check_handover_asm.py checks exactly that in the
+// code objects.
+DEV void train_release(unsigned *flags, unsigned fl, int step, unsigned xcd, int fault, unsigned blk) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && !((fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step + 1, blk)))
+        __hip_atomic_store(&flags[fl], (unsigned)(step + 1) | (xcd << TRAIN_STEP_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define TRAIN_XCC_ID() ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u) // HW_REG_XCC_ID[3:0]
+
 __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, StepArgs A, Vel4Args V, unsigned *flags, unsigned nBlocks, int fault,
                                                                     unsigned *failures) {
     __shared__ VelPostShared sh;
@@ -823,34 +867,9 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
     const unsigned slot = item % nPad;
     if (slot >= nBlocks) return;
     const unsigned blk = nBlocks - 1 - slot; // (the widest lane bucket, last in the batch, holds the long tiles: first)
-    const unsigned xcd = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u; // HW_REG_XCC_ID[3:0]
+    const unsigned xcd = TRAIN_XCC_ID();
     int bad = 0;
-    if (step > 0) {
-        if (threadIdx.x == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned seen;
-            while (((seen = __hip_atomic_load(&flags[TRAIN_FLAG_WORDS + blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & TRAIN_STEP_MASK) < (unsigned)step) {
-                __builtin_amdgcn_s_sleep(32);
-                // one wait that ran into the limit ends every later wait of the launch at once (flags[1]): the launch drains in
-                // milliseconds with REM2D_ERR_HANDOVER on what it touched instead of stalling 2 s per item
-                if (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TRAIN_WAIT_TICKS) {
-                    __hip_atomic_store(&flags[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bad = 1;
-                    break;
-                }
-            }
-            if ((seen >> TRAIN_STEP_BITS) != xcd) bad = 1; // the block's previous step ran on another XCD: its stores may still sit in that L2
-            if (!(fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step, blk)) bad = 1;
-            // the host learns of it without reading the arena: a counter in pinned host memory (rem2d_world_handover_failures)
-            if (bad) __hip_atomic_fetch_add(failures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        bad = __builtin_amdgcn_readfirstlane(bad);
-        // ACQUIRE, explicit: this CU's vector L1 and the scalar data cache (a 64-lane creature's per-creature words are uniform
-        // loads) forget what they hold from an earlier step of the block; the XCD's L2 is current.  tools/check_handover_asm.py
-        // holds the compiled kernel to this sequence (the poll loop, then buffer_inv sc1 + s_dcache_inv, before any other load).
-        asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    if (step > 0) bad = train_acquire(flags, TRAIN_FLAG_WORDS + blk, step, xcd, fault, blk, failures);
     unsigned block = blk;
     const int b = batch_find(B, block);
     BATCH_DISPATCH(pre_intile_body)
@@ -869,14 +888,78 @@ __global__ __launch_bounds__(WAVE, 4) void rem2d_step_train_kernel(Batch B, Step
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     BATCH_DISPATCH(post_toi_body, sh.p, ts1, bad)
-    // RELEASE, explicit: a workgroup-scope fence emits NO wait for outstanding stores on gfx950 (the CU's own L1 is coherent for its
-    // own wavefronts, so LLVM needs none) -- but the reader of this flag runs on ANOTHER CU of the XCD.  vmcnt counts stores as well
-    // as loads here (no vscnt before gfx10) and a store leaves the count when the XCD's L2 has acknowledged it: after this wait
-    // every store of the item -- of every lane: one wavefront, one counter -- is in the L2 the next step reads from.  The flag store
-    // must follow with no store of the item's state in between; tools/check_handover_asm.py checks exactly that in the code object.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0 && !((fault & TRAIN_FAULT_DROP) && train_fault_hits(fault, step + 1, blk)))
-        __hip_atomic_store(&flags[TRAIN_FLAG_WORDS + blk], (unsigned)(step + 1) | (xcd << TRAIN_STEP_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    train_release(flags, TRAIN_FLAG_WORDS + blk, step, xcd, fault, blk);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The step train for the 128-lane tile shapes (1: flexible placement, populations from ~130 000 creatures on; 4: the static phase ->
+// set map of uniform populations): an item = one velocity TILE = the tile's one or two 64-lane blocks.  A kernel of its own, not a
+// parameter of the one above: shared in one body (round 5) the item -> world walk and the loops over a tile's blocks cost the 64-lane
+// train 5 %.  Per item: find the world and the tile; wait for the tile's previous step; `pre` block by block; the velocity tile (two
+// joint register sets, 128 bodies in the mailbox); `post` + the TOI solve block by block; publish.  Tables must be regular
+// (State::tileCap creatures per tile, a whole number of blocks or a divisor of one -- rem2d_world_set_tiles); nItems = the tiles of
+// one step summed over the worlds (rem2d.hip train_items does the same sum).  Same device functions, same order per creature: same
+// bits.  The hand-over is the one above (train_acquire / train_release), the flag is per item.
+// ---------------------------------------------------------------------------------------------------
+struct Train128Shared {
+    union {
+        Vel4Shared<2, 2> v;
+        PosShared p;
+    };
+};
+template <bool FLEXP, int WPS>
+__global__ __launch_bounds__(WAVE, WPS) void rem2d_step_train128_kernel(Batch B, StepArgs A, Vel4Args V, unsigned *flags, unsigned nItems, int fault,
+                                                                         unsigned *failures) {
+    __shared__ Train128Shared sh;
+    __shared__ ToiSharedT<1> ts1;
+    const unsigned nPad = (nItems + 7u) & ~7u;
+    const unsigned item = blockIdx.x;
+    const int step = (int)(item / nPad);
+    const unsigned slot = item % nPad;
+    if (slot >= nItems) return;
+    const unsigned idx = nItems - 1 - slot; // (the widest lane bucket, last in the batch, holds the long tiles: first)
+    // the item's world, its tile `it` there and the tile's blocks [blk0, blk0 + nb)
+    unsigned it = idx;
+    int b = 0;
+    unsigned bpt = 1, blocksW = 0;
+    for (;; ++b) {
+        blocksW = B.blockEnd[b] - (b ? B.blockEnd[b - 1] : 0u);
+        const unsigned lanesPerTile = (unsigned)B.S[b].tileCap * (unsigned)B.lanes[b];
+        bpt = lanesPerTile > WAVE ? lanesPerTile / WAVE : 1u;
+        const unsigned itemsW = (blocksW + bpt - 1) / bpt;
+        if (it < itemsW || b + 1 >= B.n) break;
+        it -= itemsW;
+    }
+    const unsigned blk0 = it * bpt, nb = blk0 + bpt <= blocksW ? bpt : blocksW - blk0;
+    const unsigned xcd = TRAIN_XCC_ID();
+    int bad = 0;
+    if (step > 0) bad = train_acquire(flags, TRAIN_FLAG_WORDS + idx, step, xcd, fault, idx, failures);
+    for (unsigned p = 0; p < nb; ++p) {
+        unsigned block = blk0 + p;
+        BATCH_DISPATCH(pre_intile_body)
+    }
+    // what pre wrote per block lane is read per tile lane (constraints) below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {
+        const int K = B.lanes[b];
+        const unsigned cpb = (unsigned)(WAVE / K), cap = (unsigned)B.S[b].tileCap;
+        // a tile of whole blocks: tile `it`; tiles inside one block (a small world): the block's tiles
+        const bool whole = cap * (unsigned)K > WAVE;
+        const unsigned ta = whole ? it : blk0 * cpb / cap, tb = whole ? it + 1 : (blk0 + 1) * cpb / cap;
+        for (unsigned t = ta; t < tb && t < (unsigned)B.S[b].nTiles; ++t) {
+            vel4_body<2, 2, 1, false, FLEXP>(B.S[b], B.T[b].friction, V, t, K, sh.v);
+            lds_sync(); // (the next tile / the position solver reuse the mailbox)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (unsigned p = 0; p < nb; ++p) {
+        unsigned block = blk0 + p;
+        BATCH_DISPATCH(post_toi_body, sh.p, ts1, bad)
+        lds_sync(); // (the next block's position solver reuses the mailbox)
+    }
+    train_release(flags, TRAIN_FLAG_WORDS + idx, step, xcd, fault, idx);
 }
 
 #endif

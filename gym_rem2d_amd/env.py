@@ -77,6 +77,9 @@ class BatchedModular2D:
     BIG_POPULATION = 131072     # creatures per GPU from which the 128-lane tiles of the velocity kernel pay (round 4: 2 joint
                                 # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
     REBALANCE_EVERY = 50        # env-steps between two re-orderings of a mixed population by current cost (see __init__)
+    TRAIN128_MAX = 200000       # creatures per GPU up to which the 128-lane step train beats per-step launches (profiles/r05_step_train.txt 8,
+                                # profiles/r06_train128.txt)
+    TRAIN128_UNIFORM = True     # uniform populations on the static 128-lane shape: the train as well (profiles/r06_train128.txt)
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False, options=None, on_handover="raise"):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
@@ -214,11 +217,25 @@ class BatchedModular2D:
         # The step train (the library's default launch form for 64-lane tiles, REM2D_OPT_FUSE_VELPOST = 2: all steps of a call in
         # one launch, block-steps handed from workgroup to workgroup) is ONE in-order train: it wants the whole population in one
         # group (config 3: 64.8 M env-steps/s with one group, 59 M with two, 39 M with four -- profiles/r05_step_train.txt).
+        # Round 6: the 128-lane tile shapes have a train of their own (rem2d_step_train128_kernel: an item = a tile's two blocks).  It
+        # wins while a step is bound by the chain of its launches and loses once the chip's instruction issue saturates: shape 1
+        # up to TRAIN128_MAX creatures (beyond: per-step launches on four step groups, as before); shape 4 (uniform populations) --
+        # see TRAIN128_UNIFORM.
         opts = dict(_lib.env_options(), **self.options)
-        train = (shape == 3 or (shape is None and _lib.env_tile_shape() == 3)) and not retile and \
+        eff_shape = shape if shape is not None else _lib.env_tile_shape()
+        self._launch_options = {}
+        if "fuse_velpost" not in opts and ((eff_shape == 1 and n_envs > self.TRAIN128_MAX) or (eff_shape == 4 and not self.TRAIN128_UNIFORM)):
+            self._launch_options["fuse_velpost"] = 1   # (per-step launches; no result depends on it)
+            opts["fuse_velpost"] = 1
+        train = eff_shape in (3, 1, 4) and not retile and \
             opts.get("fuse_velpost", 2) == 2 and opts.get("pipeline", 3) == 3 and opts.get("debug", 0) == 0
         if train and self.step_groups <= 0:
-            groups = 1
+            groups = 1      # ... unless its lane buckets, cut into worlds of <= MAX_WORLD_LANES lanes, are more than one launch takes
+
+            def worlds_per_group(g):
+                return sum(-(-(-(-m.n_envs // g)) // max(1, self.MAX_WORLD_LANES // m.lanes)) for m, _ in batches)
+            while groups < _lib.MAX_STEP_GROUPS and worlds_per_group(groups) > _lib.MAX_WORLDS_PER_STEP:
+                groups += 1
         self._world_flags = (self.flags | _lib.FLAG_RETILE) if retile else (self.flags & ~_lib.FLAG_RETILE)
         every = self.rebalance_every
         if every < 0:
@@ -270,7 +287,7 @@ class BatchedModular2D:
                 w.set_outputs(self._reward, self._done, idx.to(torch.int32))
 
     def _world_options(self):
-        opts = dict(self.options)
+        opts = dict(getattr(self, "_launch_options", {}), **self.options)
         if self._rebalance_steps > 0:
             opts.setdefault("rebalance", self._rebalance_steps)
         return opts or None
