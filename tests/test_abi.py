@@ -142,7 +142,9 @@ def test_step_train_handover_sequences_in_the_code_objects(lib):
         rep = H.check_library(path)
         assert len(rep) >= 1
         for sym, r in rep.items():
-            assert r["polls"] >= 1 and r["publish_waitcnt"] and r["resources"]["vgprs"] <= 128, (path, sym, r)
+            # (4 wavefronts per SIMD = 128 VGPRs; the static 128-lane shape's train is compiled for 3 = 168)
+            assert r["polls"] >= 1 and r["publish_waitcnt"] and r["resources"]["vgprs"] <= (168 if "ILb0ELi3EE" in sym else 128), (path, sym, r)
+        assert len(rep) == 3, "rem2d_step_train_kernel and the two rem2d_step_train128_kernel instantiations"
     # negative controls on the default build's kernel(s)
     with tempfile.TemporaryDirectory() as wd:
         co = H.code_object(lib.LIB_PATH, wd)
