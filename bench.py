@@ -58,6 +58,13 @@ def valu_flops_per_env_step(n_bodies, vel_iters=180):
     return vel_iters * (105.0 * np.maximum(M - 1, 0) + 150.0 * 0.5 * M)
 
 
+# the hardware's VALU issue ceiling: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 v_fma_f32 (MI355X_MICROARCH.md "Per-instruction cycle
+# constants": `v_fma_f32` (wave64) 2 cyc on a SIMD-32)
+HW_VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
+# ... and what fully independent instruction streams measure on the box (tools/ubench_latency.hip mode 4 -> profiles/r06_ubench_issue.txt)
+UBENCH_INDEPENDENT = {"source": "profiles/r06_ubench_issue.txt", "wave_instructions_per_s": None}
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_round.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
@@ -407,6 +414,31 @@ REFERENCE_PYTHON_OVERHEAD = {"step_us_color_control_on": 2287, "step_us_color_co
                                        "Box2D not included"}
 
 
+def n1_reference():
+    """The committed single-GPU line of the driver's command that a multi-GPU line is compared with (newest round first)."""
+    for name in ("r06_bench_default.json", "r05_bench_step_train_default.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.loads(f.read().strip().splitlines()[-1])
+            if d.get("n_gpus") == 1 and d.get("creatures_total") == 65536:
+                return {"value": d["value"], "source": "profiles/" + name}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
+def scaling_claim(world, strong, total, per_gpu, value):
+    ref = n1_reference()
+    out = {"north_star": ">= 6x at 8 GPUs", "judged_on": "weak scaling: 65 536 creatures per GPU, creatures_total = N x 65 536 (config 5's "
+                                                         "sharding: independent individuals, one fitness all-gather)",
+           "this_line": "strong" if strong else "weak", "creatures_total": total, "creatures_per_gpu": per_gpu,
+           "n1_reference": ref, "vs_n1": (value / ref["value"]) if ref else None,
+           "expected": "weak: ~N x the single-GPU figure (no per-step collective; one 8 B/individual all-gather per block); strong "
+                       "(65 536 creatures in all): ~1.2x at 8 GPUs -- a GPU steps an eighth of the population in 0.83 ms against 0.97 ms "
+                       "for all of it, the step train is as long as its heaviest creature's own chain (DESIGN.md 7)"}
+    return out
+
+
 def launch_ranks(args):
     """`bench.py --gpus N` without a launcher around it: start N ranks with torch.distributed.run as a CHILD process
     (this parent has not touched the GPU -- no torch import, no HIP call -- and never execs) and relay its output.
@@ -550,6 +582,9 @@ def main():
     secondary_in = {wl: finish_population(p) for wl, p in secondary_in.items()}
     if generation:
         workload_desc = "one EA generation: whole episodes (evaluate() rule, <= 2500 steps) of " + workload_desc
+    if world > 1:   # (the population `value` is quoted on, in the workload's own name)
+        workload_desc = ("%d creatures in all = %d ranks x %d (%s scaling); this rank: " % (total, world, n_envs, "strong" if strong else "weak")) \
+            + workload_desc
 
     import torch
     import torch.distributed as dist
@@ -663,9 +698,9 @@ def main():
     if pipeline == 3:
         # (the library's answer: velocity tiles and position iterations of a 64-lane block in ONE launch -- then that launch,
         # rem2d_velpost_kernel, is the dominant kernel and what the HIP events above timed)
-        _, fused_velpost = env.launch_info()
+        launch_shape, fused_velpost = env.launch_info()
         if fused_velpost == 2:     # the step train: all steps of a call and all phases of a step in one launch
-            kname = "rem2d_step_train_kernel"
+            kname = "rem2d_step_train128_kernel" if launch_shape in (1, 4) else "rem2d_step_train_kernel"
         elif fused_velpost:
             kname = "rem2d_velpost_kernel"
     bytes_per_step = float(sum(algorithmic_bytes(m.n_bodies).sum() for m in morphs))
@@ -689,6 +724,8 @@ def main():
         if pe.get("SQ_INSTS_VALU") and tc.get("step_groups") == n_groups:
             issue = {"wave_instructions_per_env_step": pe["SQ_INSTS_VALU"], "peak_wave_instructions_per_s": 860e9,
                      "active_lanes_per_valu_inst": tc.get("active_lanes_per_valu_inst"),
+                     "scalar_instructions_per_env_step": pe.get("SQ_INSTS_SALU"),
+                     "wait_frac_of_wave_cycles": (pe["SQ_WAIT_ANY"] / pe["SQ_WAVE_CYCLES"]) if pe.get("SQ_WAVE_CYCLES") else None,
                      "source": "%s (per env-step of this population), profiles/r02_b_ubench_valu_latency.txt" % traffic_src}
     else:
         traffic_bytes, traffic_src = pmc_traffic(kname) if headline else (None, None)
@@ -698,6 +735,13 @@ def main():
     if issue:
         issue["achieved_wave_instructions_per_s"] = issue["wave_instructions_per_env_step"] * args.steps / dt
         issue["frac"] = issue["achieved_wave_instructions_per_s"] / issue["peak_wave_instructions_per_s"]
+        # two ceilings, both printed: `peak_wave_instructions_per_s` / `frac` = what DEPENDENT chains reach on this
+        # chip (tools/ubench_latency.hip, 8 chains per SIMD) -- the shape of a Gauss-Seidel sweep; `hw_*` = the hardware's VALU issue
+        # rate, wave64 v_fma_f32 at 2 cycles on each of 1024 SIMD-32s at 2.4 GHz (MI355X_MICROARCH.md, cycle constants), which only
+        # independent instruction streams reach (measured: UBENCH_INDEPENDENT below)
+        issue["hw_peak_wave_instructions_per_s"] = HW_VALU_ISSUE_PEAK
+        issue["hw_frac"] = issue["achieved_wave_instructions_per_s"] / HW_VALU_ISSUE_PEAK
+        issue["ubench_independent_streams"] = UBENCH_INDEPENDENT
 
     # ---- secondary workloads, same process: north_star's "8-module creatures" and config 4 ----
     secondary = None
@@ -757,6 +801,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
+            # north_star's ">= 6x scaling at 8 GPUs" is judged on WEAK scaling (65 536 creatures per GPU = config 5's sharding);
+            # the line carries the single-GPU figure it is compared with (the driver computes the efficiency itself from its own runs)
+            "scaling_claim": scaling_claim(world, strong, total, n_envs, total * args.steps / dt)
+            if args.workload == "lsystem" and not args.discrete and not args.envs else None,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -778,7 +826,7 @@ def main():
                                       "fitness all-gather per block (%s)" % (world, backend if world > 1 else "none at 1 rank"),
                        "ranks_share_one_gpu": bool(world > 1 and n_dev < world),
                        "shard_cost_bodies": shard_cost,   # per rank: bodies in its shard (the static cost key of evaluate.shard_balanced)
-                       "merged_launch": bool(merged), "step_groups": n_groups, "hip_graph": bool(env.use_graph),
+                       "merged_launch": bool(merged), "step_groups": n_groups, "launch": kname, "hip_graph": bool(env.use_graph),
                        # every block = exactly `steps` env-steps between barrier + synchronize; value = median block
                        "blocks": len(blocks), "blocks_ms": [round(x * 1e3, 3) for x in blocks],
                        "block_ms_median": dt * 1e3, "block_ms_first": blocks[0] * 1e3, "block_ms_min": min(blocks) * 1e3,
@@ -801,6 +849,9 @@ def main():
                          "valu_tflops_est": valu, "valu_frac_of_157.3": valu / 157.3,
                          # the roof this path actually runs under: VALU wave-instruction issue (at ~10 of 64 lanes)
                          "valu_issue": issue,
+                         # (top level as well: the two figures that say how the chip is used -- of 64 lanes, and of a resident wavefront's cycles)
+                         "active_lanes_per_valu_inst": issue.get("active_lanes_per_valu_inst") if issue else None,
+                         "wait_frac_of_wave_cycles": issue.get("wait_frac_of_wave_cycles") if issue else None,
                          "note": "algorithmic bytes B(M,C)=72M+100(M-1)+48C+12, C=2M per env-step (SURVEY 8d), all of them "
                                  "charged to the dominant kernel; the path is bound by the per-wavefront issue interval over "
                                  "the 180+60 Gauss-Seidel sweeps (FP32 VALU; valu_issue.frac of the issue "

@@ -431,6 +431,9 @@ __global__ __launch_bounds__(WAVE) void rem2d_post_multi_kernel(Batch B, StepArg
 // measured the same at config 3's world sizes), more for bigger worlds so that a thread's chunk stays at <= 256 creatures
 // (a 262 144-creature world of a 1 M-individual generation: 1 024 threads).
 #define REBALANCE_MAX_THREADS 1024
+#ifdef REBALANCE_VEL
+#define REBALANCE_CLASSES (3 * REBALANCE_VEL)
+#endif
 #ifndef REBALANCE_CLASSES
 #define REBALANCE_CLASSES 3 // (three classes under the step train: +0.7 % on config 3 over two, config 4 unchanged; profiles/r05_step_train.txt)
 #endif
@@ -453,10 +456,31 @@ __global__ __launch_bounds__(REBALANCE_MAX_THREADS) void rem2d_rebalance_kernel(
     int c[REBALANCE_CLASSES];
 #pragma unroll
     for (int k = 0; k < REBALANCE_CLASSES; ++k) c[k] = 0;
+#ifdef REBALANCE_VEL
+    // (experiment, round 6: the cost of the VELOCITY tile as a second key -- a tile pays, per iteration, as many contact sub-slots as
+    // its most loaded creature: the most manifolds on one body (phase 0 after the rotation) plus one tick per further touching body.
+    // Read from the last step's `pre` hand-over words of the creature's lanes.)
+    const int K = (int)(S.Lp / S.Np);
+    auto key_of = [&](int e) -> int {
+        const unsigned env = (unsigned)e;
+        int maxT = 0, nTouching = 0;
+        for (int l = 0; l < K; ++l) {
+            const int m = __float_as_int(SW((unsigned)SCR_MISC_BASE * S.Lp + (unsigned)(e * K + l), 0));
+            const int nT = (m & 0x100) ? (m & 0xff) : 0;
+            maxT = max(maxT, nT);
+            nTouching += nT > 0 ? 1 : 0;
+        }
+        const int vel = min(REBALANCE_VEL - 1, maxT + min(nTouching > 0 ? nTouching - 1 : 0, 2)); // 0 .. REBALANCE_VEL - 1
+        const int pos = EI(E_POSITERS) >= posIters ? 0 : (EI(E_POSITERS) >= 3 ? 1 : 2);
+        return pos * REBALANCE_VEL + (REBALANCE_VEL - 1 - vel); // (the expensive ones first inside a position class)
+    };
+#define rebalance_class(key, posIters) (key)
+#else
     auto key_of = [&](int e) -> int {
         const unsigned env = (unsigned)e;
         return EI(E_POSITERS);
     };
+#endif
     for (int e = lo; e < hi; ++e) {
         const int cls = rebalance_class(key_of(e), posIters);
 #pragma unroll
@@ -491,6 +515,9 @@ __global__ __launch_bounds__(REBALANCE_MAX_THREADS) void rem2d_rebalance_kernel(
         S.order[S.Np + p] = e;
     }
     for (int e = n + t; e < (int)S.Np; e += T) { S.order[e] = e; S.order[S.Np + e] = e; } // padding creatures keep their slots
+#ifdef REBALANCE_VEL
+#undef rebalance_class
+#endif
 }
 
 // (Round 3 built "rest": post + the TOI solve of the wavefront's own bodies + the next step's pre in one launch, two

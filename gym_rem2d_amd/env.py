@@ -77,9 +77,10 @@ class BatchedModular2D:
     BIG_POPULATION = 131072     # creatures per GPU from which the 128-lane tiles of the velocity kernel pay (round 4: 2 joint
                                 # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
     REBALANCE_EVERY = 50        # env-steps between two re-orderings of a mixed population by current cost (see __init__)
-    TRAIN128_MAX = 200000       # creatures per GPU up to which the 128-lane step train beats per-step launches (profiles/r05_step_train.txt 8,
-                                # profiles/r06_train128.txt)
-    TRAIN128_UNIFORM = True     # uniform populations on the static 128-lane shape: the train as well (profiles/r06_train128.txt)
+    TRAIN128_MAX = 163840       # creatures per GPU up to which the 128-lane step train beats per-step launches (profiles/r06_train128.txt:
+                                # 131 072: 71.5 vs 69.6 M env-steps/s; 196 608: 77.6 vs 80.7 M)
+    TRAIN128_UNIFORM = False    # uniform populations on the static 128-lane shape keep per-step launches on three step groups: 65 536 8-module
+                                # chains 180.7 M against 177.0 M as a train (and 142.5 M as a 64-lane train) -- profiles/r06_train128.txt
 
     def __init__(self, hardcore=False, flat=False, seed=4, device=None, flags=None, wide=False, options=None, on_handover="raise"):
         # pybox2d's b2World() defaults: continuousPhysics on, sleeping on
