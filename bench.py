@@ -101,7 +101,7 @@ def pmc_traffic_all():
 def valu_issue(n_groups):
     """VALU wave-instructions per env-step of the default population from the committed SQ-counter pass
     (profiles/r05_sq_counters.json: SQ_INSTS_VALU per launch of one step group, tools/profile_round.sh) and the chip's
-    measured issue peak (tools/ubench_latency.hip -> profiles/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s
+    measured issue peak (tools/ubench_latency.hip -> profiles/archive/r02_b_ubench_valu_latency.txt: 860 G wave-instructions/s
     with 8 dependent chains per SIMD).  Only when this run uses the step-group count the counters were collected with."""
     for name in ("r05_sq_counters.json", "r04_sq_counters.json", "r03_sq_counters.json", "r02_b_sq_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
@@ -117,12 +117,12 @@ def valu_issue(n_groups):
                         if k.startswith(("rem2d_pre", "rem2d_vel4", "rem2d_velpost", "rem2d_post", "rem2d_toi", "rem2d_step_train")))
         return {"wave_instructions_per_env_step": per_group * n_groups, "peak_wave_instructions_per_s": 860e9,
                 "source": "profiles/%s (per launch of one of the %d step groups of this command), "
-                          "profiles/r02_b_ubench_valu_latency.txt" % (name, n_groups)}
+                          "profiles/archive/r02_b_ubench_valu_latency.txt" % (name, n_groups)}
     return None
 
 
 def train_counters():
-    """The committed counter passes of the step train (tools/r05_train_profile.sh -> profiles/r05_step_train_counters.json): per
+    """The committed counter passes of the step train (tools/train_profile.sh -> profiles/<round>_step_train_counters.json): per
     env-step of the headline population -- HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) and VALU
     wave-instructions."""
     path = os.path.join(ROOT, "profiles", "r05_step_train_counters.json")
@@ -726,7 +726,7 @@ def main():
                      "active_lanes_per_valu_inst": tc.get("active_lanes_per_valu_inst"),
                      "scalar_instructions_per_env_step": pe.get("SQ_INSTS_SALU"),
                      "wait_frac_of_wave_cycles": (pe["SQ_WAIT_ANY"] / pe["SQ_WAVE_CYCLES"]) if pe.get("SQ_WAVE_CYCLES") else None,
-                     "source": "%s (per env-step of this population), profiles/r02_b_ubench_valu_latency.txt" % traffic_src}
+                     "source": "%s (per env-step of this population), profiles/archive/r02_b_ubench_valu_latency.txt" % traffic_src}
     else:
         traffic_bytes, traffic_src = pmc_traffic(kname) if headline else (None, None)
         traffic = traffic_bytes / (avg_ms * 1e-3) / 1e9 if (traffic_bytes and avg_ms > 0) else None

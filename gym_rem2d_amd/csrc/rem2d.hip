@@ -181,7 +181,7 @@ static int default_tile_creatures(const TileShape &shp, int lanes) {
 //                  driver's command (one launch per step and group less to wait for at the join of every call)
 //   PRIO           issue priority (s_setprio) for the wavefronts expected to be the long ones of their launch -- bit 1: the
 //                  velocity tiles with the most slots per iteration (cost 7 ticks + 10 sub-slots >= PRIO_T1: priority 1,
-//                  >= PRIO_T2: priority 3), bit 4: the wavefronts of the TOI solve.  profiles/r03_prio.txt: config 3 +4.6 %
+//                  >= PRIO_T2: priority 3), bit 4: the wavefronts of the TOI solve.  profiles/archive/r03_prio.txt: config 3 +4.6 %
 //   HEAVY_PER_WAVE bodies of the TOI work list per wavefront of rem2d_toi_heavy_multi_kernel, 1..64 (one: a wavefront that
 //                  holds two runs the union of their code paths)
 //   DEBUG          diagnostic builds (-DREM2D_V4_PROBES) only: Vel4Args::dbg

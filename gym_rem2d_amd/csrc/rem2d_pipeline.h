@@ -233,7 +233,7 @@ DEV int wave_or(int v) {
 // -- those that used every iteration from the FRONT of the order (their wavefronts are the long ones: they must be
 // dispatched first), the others from the back (one atomic per wavefront and class) -- so that ~12 % of the wavefronts
 // run 60 iterations instead of ~70 %.  Same arithmetic on the same operands: same bits, whatever order the atomics
-// produce.  Measured (profiles/r03_retile.txt): -34 % VALU wave-instructions in this kernel (61.9 -> 41.1 M per launch),
+// produce.  Measured (profiles/archive/r03_retile.txt): -34 % VALU wave-instructions in this kernel (61.9 -> 41.1 M per launch),
 // but a wavefront of eight such creatures with different periods runs a contact AND a joint section in every tick, so
 // the slowest wavefront -- the kernel's duration -- gets longer: +4.4 % env-steps/s where the chip's instruction issue
 // is the limit (131 072 creatures per GPU, config 5's share), -5 % where the chain of kernels is (65 536).  Hence a
@@ -522,6 +522,6 @@ __global__ __launch_bounds__(REBALANCE_MAX_THREADS) void rem2d_rebalance_kernel(
 
 // (Round 3 built "rest": post + the TOI solve of the wavefront's own bodies + the next step's pre in one launch, two
 // launches per step instead of four.  Bit-exact, but it needs the TOI solve's 256 VGPRs and was slower on every workload:
-// profiles/r03_fused_rest.txt.  Removed; post_body keeps the FUSED hook it used.)
+// profiles/archive/r03_fused_rest.txt.  Removed; post_body keeps the FUSED hook it used.)
 
 #endif

@@ -326,7 +326,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     // (3) the period itself is a choice: the schedule is valid for any period >= the creatures' own (compiler.pipeline_schedule),
     //     and one more tick per iteration widens every body's window by one, so that bodies whose windows did not meet can
     //     share a contact tick.  A tile whose contact sub-slots outweigh a joint slot takes the longer period: the slowest
-    //     tiles of a launch are such tiles (period 3-4 with 5-6 sub-slots per iteration, profiles/r03_slow_tiles.txt).
+    //     tiles of a launch are such tiles (period 3-4 with 5-6 sub-slots per iteration, profiles/archive/r03_slow_tiles.txt).
     //     Again only with one joint register set.
     const unsigned long long groupLanes = (K >= WAVE ? ~0ull : ((1ull << K) - 1ull)) << (lane & ~(K - 1) & (WAVE - 1));
     int offB[PASSES], delta[PASSES];
@@ -400,14 +400,20 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
     };
     {
         const int subsP = plan(P);
-        // a joint slot costs ~0.7 of a HEAVY contact sub-slot (profiles/r03_slow_tiles.txt: 850-1000 vs 1150-1400 cycles) but
+        // a joint slot costs ~0.7 of a HEAVY contact sub-slot (profiles/archive/r03_slow_tiles.txt: 850-1000 vs 1150-1400 cycles) but
         // about as much as a light one (800): only a gain of two sub-slots is worth a tick.  (Longer periods still -- up to
         // the creatures' round count, where every window contains one common tick -- need the tick loop rolled instead of
         // unrolled per phase; measured: the rolled loop costs 4 % per tick, more than the few tiles it helps gain.)
         if (FLEX && P < V4_PHASES && subsP >= 3) {
+            int offP[PASSES], deltaP[PASSES]; // (the plan for P, kept: trying P + 1 overwrites it, and evaluating a plan is ~1 000 instructions)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) { offP[p] = offB[p]; deltaP[p] = delta[p]; }
             const int subsQ = plan(P + 1);
             if (subsQ + 2 <= subsP) P = P + 1;
-            else (void)plan(P); // (back to the plan for P)
+            else {
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) { offB[p] = offP[p]; delta[p] = deltaP[p]; } // (back to the plan for P)
+            }
         }
     }
 #pragma unroll

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: instruction mix and LDS behaviour of the step kernels (one --pmc pass per counter group; counters only + --kernel-trace)
 set -u
-O=$GRAFT_REPO_ROOT/gpurun_out/r05_pmc_extra; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/pmc_passes; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ARGS="--steps 10 --warmup 2 --settle 80 --no-cpu-baseline --no-secondary --min-time 0"
 python3 bench.py $ARGS > /dev/null 2>&1

@@ -30,4 +30,4 @@ timeout 600 python tools/soak_parity.py --n 6000 --steps 300 > $O/soak_parity.tx
 timeout 600 python tools/fuzz_launch_shapes.py --rounds 40 --seed 1 > $O/fuzz_launch_shapes.txt 2>&1; tail -1 $O/fuzz_launch_shapes.txt
 timeout 600 python tools/fuzz_episode.py --rounds 30 --seed 1 > $O/fuzz_episode.txt 2>&1; tail -1 $O/fuzz_episode.txt
 timeout 900 python3 tools/fma_tolerance.py --n 1024 --steps 150 > $O/fma_tolerance.txt 2>&1; tail -6 $O/fma_tolerance.txt
-bash tools/r05_bench_ea.sh 1048576 > $O/bench_ea.txt 2>&1; cp gpurun_out/r05_bench_ea/bench_ea_*.json $O/ 2>/dev/null; cat $O/bench_ea.txt
+bash tools/archive/r05_bench_ea.sh 1048576 > $O/bench_ea.txt 2>&1; cp gpurun_out/r05_bench_ea/bench_ea_*.json $O/ 2>/dev/null; cat $O/bench_ea.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Reduce the counter passes of tools/r05_train_profile.sh: per 50-step launch of rem2d_step_train_kernel (the modal grid size) and
-per env-step of the population -> JSON on stdout (profiles/r05_step_train_counters.json, read by bench.py)."""
+"""Reduce the counter passes of tools/train_profile.sh: per 50-step launch of rem2d_step_train_kernel (the modal grid size) and
+per env-step of the population -> JSON on stdout (profiles/<round>_step_train_counters.json, read by bench.py)."""
 import collections
 import csv
 import glob
@@ -25,7 +25,7 @@ for (f, d, g), cs in acc.items():
             per[c].append(v)
 launch = {c: sum(v) / len(v) for c, v in per.items()}
 res = {"command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 50 --warmup 40 --settle 60 --steps-per-launch 50 "
-                  "--no-cpu-baseline --no-secondary --min-time 0 (one pass per counter group, tools/r05_train_profile.sh)",
+                  "--no-cpu-baseline --no-secondary --min-time 0 (one pass per counter group, tools/train_profile.sh)",
        "kernel": "rem2d_step_train_kernel", "steps_per_launch": STEPS, "grid_size": modal,
        "launches_averaged": {c: len(v) for c, v in per.items()}, "per_launch": launch, "step_groups": 1}
 pe = {c: v / STEPS for c, v in launch.items()}
