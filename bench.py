@@ -62,7 +62,11 @@ def valu_flops_per_env_step(n_bodies, vel_iters=180):
 # constants": `v_fma_f32` (wave64) 2 cyc on a SIMD-32)
 HW_VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 # ... and what fully independent instruction streams measure on the box (tools/ubench_latency.hip mode 4 -> profiles/r06_ubench_issue.txt)
-UBENCH_INDEPENDENT = {"source": "profiles/r06_ubench_issue.txt", "wave_instructions_per_s": None}
+UBENCH_INDEPENDENT = {"source": "profiles/r06_ubench_issue.txt (tools/ubench_latency.bin: eight independent v_fma_f32 accumulators per wavefront)",
+                      "wave_instructions_per_s_at_4_waves_per_simd": 856e9, "wave_instructions_per_s_at_8_waves_per_simd": 955e9,
+                      "note": "the step train runs at 4 wavefronts per SIMD (128 VGPRs): 856 G/s is what the hardware issues there even for "
+                              "fully independent streams; 955 G/s needs 8 wavefronts per SIMD (<= 64 VGPRs); the guide's 1 229 G/s (2 cycles per "
+                              "wave64 v_fma_f32 at 2.4 GHz) was not reached by any stream on this box"}
 
 
 def pmc_traffic(kernel_name):

@@ -819,6 +819,10 @@ static void tiles_plan(TilePlan &P, rem2d_world *const *ws, int n_worlds, float 
             const rem2d_world *w = ws[i];
             P.train128 = P.train128 && !(w->cfg.flags & REM2D_FLAG_RETILE) && w->S.tileCap > 0 && w->S.tileCap * w->cfg.lanes <= 2 * WAVE &&
                          (w->tileShape == 3 || w->tileShape == 1 || w->tileShape == 4);
+            // the static kernel keeps the ARENA order in its velocity tiles (the host planned them for the creatures they hold) while
+            // pre and post follow the creature order: under an order a tile's creatures are not the ones this workgroup's pre / post
+            // handle -- legal between launches, not inside one workgroup.  Such worlds keep their per-step launches.
+            if (P.launchShape == 4 && (w->S.flags & REM2D_STATE_ORDERED)) P.train128 = false;
             const unsigned lanesPerTile = (unsigned)w->S.tileCap * (unsigned)w->cfg.lanes, bpt = lanesPerTile > WAVE ? lanesPerTile / WAVE : 1u;
             items += ((unsigned)w->L.Lp / WAVE + bpt - 1) / bpt; // (the kernel's item -> world walk does the same sum)
         }

@@ -165,3 +165,50 @@ def test_step_time_counts_env_steps(need_gpu):
     ms, n = w.step_time_ms()
     assert n == 7 and ms > 0
     w.close()
+
+
+@pytest.mark.parametrize("shape,uniform", [(1, False), (4, True), (4, False)])
+def test_train128_is_the_launch_form_and_matches_the_oracle(need_gpu, oracle, rough_terrain, shape, uniform):
+    """The 128-lane tile shapes have a step train of their own (rem2d_step_train128_kernel: an item = a tile's one or two blocks).
+    rem2d_worlds_launch_info names it (2), its result == the oracle's == per-step launches of the same shape, a forced hand-over
+    failure is flagged there too -- and the STATIC shape under a creature order keeps per-step launches (its velocity tiles hold
+    the arena order while pre / post follow the creature order: legal between launches, not inside one workgroup)."""
+    import ctypes as C
+    import torch
+    from gym_rem2d_amd import Morphology, _lib, synthetic
+    from gym_rem2d_amd.world import BatchedWorld
+    if uniform:
+        morph = synthetic.chain_population(96, 8, "left")
+    else:
+        specs = [s for s in synthetic.lsystem_specs(range(300), mutate_odd=True) if 3 <= s.n_bodies <= 8]
+        morph = Morphology.from_specs(specs, 8)
+    ref = oracle.batch_run(oracle_terrain(oracle, rough_terrain), morph.as_dict(), 150, n_threads=8, flags=oracle.FLAG_CONTINUOUS)
+
+    def info(w):
+        arr = (C.c_void_p * 1)(w.h)
+        s, f = C.c_int32(), C.c_int32()
+        _lib.check(w.L.rem2d_worlds_launch_info(arr, 1, C.byref(s), C.byref(f)))
+        return s.value, f.value
+    outs = []
+    for opts in (None, {"fuse_velpost": 1}, {"train_fault": _lib.train_fault(2, 2)}):
+        w = BatchedWorld(morph.n_envs, morph.lanes, _lib.FLAG_CONTINUOUS, options=opts)
+        w.set_terrain(rough_terrain)
+        w.reset(morph, tile_shape=shape)
+        regular = info(w)
+        assert regular == (shape, 0 if opts and "fuse_velpost" in opts else 2), regular
+        for n in (1, 49, 100):
+            w.step(n)
+        torch.cuda.synchronize()
+        outs.append(w.bodies())
+        assert np.array_equal(outs[-1], ref["bodies"])          # (a forced failure changes flags, never arithmetic)
+        assert np.array_equal(w.view("fitness").cpu().numpy(), ref["fitness"])
+        err = w.view("err").cpu().numpy()
+        if opts and "train_fault" in opts:
+            assert w.handover_failures() > 0 and ((err & _lib.ERR_HANDOVER) != 0).any() and not (err & _lib.ERR_CAPACITY).any()
+        else:
+            assert w.handover_failures() == 0 and int(err.max()) == 0
+        if opts is None and shape == 4:
+            # a creature order on the static shape: the library answers with per-step launches from here on, same bits
+            w.set_order(torch.randperm(morph.n_envs, generator=torch.Generator().manual_seed(3)))
+            assert info(w) == (4, 0)
+        w.close()

@@ -519,7 +519,7 @@ def test_option_argument_errors(gpu):
     from gym_rem2d_amd import _lib
     w = gpu(4, 4, 0)
     L = _lib.lib()
-    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 2, 5, 60, 75, 1, 0, 0]     # the documented defaults
+    assert [w.get_option(k) for k in _lib.OPTIONS] == [3, 2, 5, 60, 75, 1, 0, 0, 0]     # the documented defaults
     for key, bad in ((0, 1), (0, 2), (1, 3), (5, 0), (5, 65), (2, -1), (99, 0), (-1, 0)):
         assert L.rem2d_world_set_option(w.h, key, bad) == -1, (key, bad)
     assert b"option" in L.rem2d_last_error()

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--compare", type=int, default=8, help="launches between two full-state comparisons")
     ap.add_argument("--rebalance", type=int, default=50)
     ap.add_argument("--wide", action="store_true")
+    ap.add_argument("--tile-shape", type=int, default=-1, help="force a tile shape for both envs (1: the 128-lane flexible shape = "
+                                                               "rem2d_step_train128_kernel against per-step launches)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -53,9 +55,12 @@ def main():
                                  on_handover="raise")
             e.rebalance_every = args.rebalance
             e.step_groups = 1   # (the same worlds on both sides: per-step launches would otherwise be dealt to four step groups)
+            if args.tile_shape >= 0:
+                e.tile_shape = args.tile_shape
             e._upload(batches, args.creatures)
             envs.append(e)
-        assert envs[0].launch_info()[1] == 2 and envs[1].launch_info()[1] == 1, (envs[0].launch_info(), envs[1].launch_info())
+        # (launch_info: (tile shape, 2 = step train / 1 = velocity + position in one launch per step / 0 = two launches per step))
+        assert envs[0].launch_info()[1] == 2 and envs[1].launch_info()[1] in (0, 1), (envs[0].launch_info(), envs[1].launch_info())
         episodes += 1
         done = 0
         while done < args.episode and launches < args.launches:
@@ -84,7 +89,7 @@ def main():
                 assert envs[0].handover_failures() == 0
         for e in envs:
             e.close()
-    out = {"tool": "tools/soak_train_vs_steps.py", "creatures": args.creatures, "wide": bool(args.wide), "rebalance": args.rebalance,
+    out = {"tool": "tools/soak_train_vs_steps.py", "creatures": args.creatures, "wide": bool(args.wide), "rebalance": args.rebalance, "tile_shape": args.tile_shape,
            "abi_calls_per_env": launches, "train_kernel_launches": train_launches, "env_steps": steps, "episodes": episodes,
            "full_state_comparisons": compares, "fields_compared": len(_lib.FIELDS), "mismatches": mismatches,
            "first_mismatch": first_bad, "handover_failures": 0, "seconds": round(time.time() - t0, 1),
