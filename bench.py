@@ -129,13 +129,15 @@ def train_counters():
     """The committed counter passes of the step train (tools/train_profile.sh -> profiles/<round>_step_train_counters.json): per
     env-step of the headline population -- HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction) and VALU
     wave-instructions."""
-    path = os.path.join(ROOT, "profiles", "r05_step_train_counters.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return d, os.path.relpath(path, ROOT)
-    except Exception:  # noqa: BLE001
-        return None, None
+    for name in ("r06_step_train_counters.json", "r05_step_train_counters.json"):   # (newest round first)
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return d, os.path.relpath(path, ROOT)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
 def build_population(workload, n_envs, first):

@@ -250,12 +250,41 @@ def check_library(lib_path):
         return out
 
 
+def scratch_map(lib_path, bins=40):
+    """Where a train kernel's register spills sit: per 1/bins-th of its instructions (address order) the scratch stores / loads,
+    SGPR-spill lane moves, LDS and global memory instructions.  The layout of the step train in address order is: `pre` (six
+    lane-count instantiations), the velocity tile (one), then `post` + the TOI solve (six instantiations)."""
+    with tempfile.TemporaryDirectory() as wd:
+        co = code_object(lib_path, wd)
+        out = {}
+        for sym in train_symbols(co):
+            ins = disassemble(co, sym)
+            rows = [[0, 0, 0, 0, 0, 0] for _ in range(bins)]
+            for k, (a, m, o, t) in enumerate(ins):
+                r = rows[k * bins // len(ins)]
+                r[0] += 1
+                r[1] += m.startswith("scratch_store")
+                r[2] += m.startswith("scratch_load")
+                r[3] += m in ("v_writelane_b32", "v_readlane_b32")
+                r[4] += m.startswith("ds_")
+                r[5] += m.startswith("global_")
+            out[sym] = rows
+        return out
+
+
 def default_libraries():
     pkg = os.path.join(ROOT, "gym_rem2d_amd")
     return [os.path.join(pkg, n) for n in ("librem2d.so", "librem2d_wide.so", "librem2d_fma.so")]
 
 
 def main(argv):
+    if len(argv) > 1 and argv[1] == "--scratch-map":
+        lib = argv[2] if len(argv) > 2 else default_libraries()[0]
+        for sym, rows in scratch_map(lib).items():
+            print("# %s\n# bin instructions scratch_store scratch_load sgpr_spill_lane_moves lds global" % sym)
+            for b, r in enumerate(rows):
+                print("%2d %6d %4d %4d %4d %4d %4d" % tuple([b] + r))
+        return 0
     libs = argv[1:] or default_libraries()
     report = {}
     for p in libs:
