@@ -153,6 +153,7 @@ def reevaluate_wide(env, bad, fit, max_steps=EPISODE_CAP, chunk=100):
     """The overflow fallback (see ``reevaluate``): the creatures of ``bad`` again, from reset, in the wide build.  Writes their
     fitness into ``fit`` and returns the mask of creatures that overflowed even there."""
     codes = _resolve_handover(env, reevaluate(env, bad, fit, wide=True, max_steps=max_steps, chunk=chunk), fit, True, max_steps, chunk)
+    env.last_error_codes = codes   # (REM2D_ERR_* of the wide run, [N]: what SolverOverflow reports for the creatures still unresolved)
     return codes != 0
 
 
@@ -193,6 +194,7 @@ def run_episode_masked(env, max_steps=EPISODE_CAP, chunk=100, compact=True, fall
     if env.handover_failures(clear=True) or bool(((err & _lib.ERR_HANDOVER) != 0).any()):
         err = _resolve_handover(env, err, fit, None, max_steps, chunk)
     bad = (err & _lib.ERR_CAPACITY) != 0
+    env.last_error_codes = err
     env.last_overflow = torch.nonzero(bad).flatten().cpu().tolist()   # population indices that needed the fallback
     if fallback and bool(bad.any()):
         bad = reevaluate_wide(env, bad, fit, max_steps, chunk)
@@ -232,7 +234,7 @@ def run_episode(env, max_steps=EPISODE_CAP, chunk=100, on_error="fallback", comp
         env.last_unresolved = torch.nonzero(bad).flatten().cpu().tolist()
         if bool(bad.any()):
             idx = torch.nonzero(bad).flatten().cpu().tolist()
-            raise SolverOverflow(idx, [_lib.ERR_SOLVER_OVERFLOW] * len(idx))
+            raise SolverOverflow(idx, env.last_error_codes[bad].cpu().tolist())   # (the creatures' real REM2D_ERR_* bits of the wide run)
         return fit
     _episode(env, max_steps, chunk, compact)
     check_errors(env, on_error)   # (REM2D_ERR_HANDOVER raises HandoverError in "raise" and "warn"; so does env.fitness below)
