@@ -797,6 +797,9 @@ DEV void post_toi_body(const State &S, const Terrain &T, const StepArgs &A, unsi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     unsigned long long hm = __ballot(heavy ? 1 : 0);
+#ifdef REM2D_PROBE_SKIP_TOI // (probe build only: what the TOI solves cost the train -- WRONG physics, bodies keep their discrete poses)
+    hm = 0ull;
+#endif
     while (hm) {
         const int h = __ffsll((long long)hm) - 1;
         hm &= hm - 1;
