@@ -211,6 +211,13 @@ class BatchedModular2D:
             if shape == 3 and blocks / groups > 2048 and all(_uniform(m) for m, _ in batches):
                 shape = 4   # (128-lane tiles with the static phase -> set map: nothing to rotate in a uniform population)
         self._tile_shape_used = shape
+        # (experiment override, host layer only: a tile shape per lane bucket, "lanes:shape,..." -- e.g. the light buckets on 128-lane
+        # tiles beside the 16-lane bucket on 64-lane ones in ONE launch: the launch takes the kernel of the largest shape)
+        by_lanes = {}
+        for item in os.environ.get("REM2D_TILE_SHAPE_BY_LANES", "").split(","):
+            if ":" in item:
+                by_lanes[int(item.split(":")[0])] = int(item.split(":")[1])
+        self._tile_shape_by_lanes = by_lanes
         # REM2D_FLAG_RETILE (the position kernel deals the creatures anew in every step, in arrival order) was round 3's policy
         # for >= 98 304 creatures; the stable re-ordering every 50 steps does better there and also pays at 65 536
         # (profiles/r04_lane_fill_experiments.txt), so the flag is an experiment override now (REM2D_RETILE=1)
@@ -266,7 +273,7 @@ class BatchedModular2D:
                 part = morph if len(mem) == morph.n_envs else morph.take(mem)
                 w = BatchedWorld(part.n_envs, part.lanes, self._world_flags, self.device, wide=self.wide, options=self._world_options())
                 w.set_terrain(self._terrain())
-                w.reset(part, tile_shape=shape)
+                w.reset(part, tile_shape=self._tile_shape_by_lanes.get(part.lanes, shape))
                 self.groups[g].append(len(self.worlds))
                 self.worlds.append((w, torch.as_tensor(idx[mem], dtype=torch.long, device=w.device)))
                 self._world_morph.append(part)
