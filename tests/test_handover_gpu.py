@@ -212,3 +212,35 @@ def test_train128_is_the_launch_form_and_matches_the_oracle(need_gpu, oracle, ro
             w.set_order(torch.randperm(morph.n_envs, generator=torch.Generator().manual_seed(3)))
             assert info(w) == (4, 0)
         w.close()
+
+
+def test_back_to_back_handovers_small_population(need_gpu):
+    """The hand-over under stress: with a few hundred creatures the workgroup of a block's next step is dispatched right behind the one
+    it waits for (a big population keeps them a whole step of other items apart), so every step really polls a flag that is being
+    published.  The train against per-step launches, every arena field `==`, through 250 calls of random lengths (the same check over
+    21 000 launches: profiles/r06_train_vs_steps_soak_small.jsonl)."""
+    import torch
+    from gym_rem2d_amd import _lib, synthetic
+    from gym_rem2d_amd.env import BatchedModular2D
+    rng = np.random.default_rng(11)
+    batches = [(m, idx.tolist()) for m, idx in synthetic.lsystem_batches_native(range(5_000_000, 5_000_256), n_proc=1)]
+    envs = []
+    for fuse in (2, 1):
+        e = BatchedModular2D(seed=4, flags=_lib.FLAG_CONTINUOUS, options={"fuse_velpost": fuse})
+        e.rebalance_every, e.step_groups = 50, 1
+        e._upload(batches, 256)
+        envs.append(e)
+    assert envs[0].launch_info()[1] == 2 and envs[1].launch_info()[1] == 1
+    for call in range(250):
+        n = int(rng.integers(1, 25))
+        for e in envs:
+            e.step(n)
+        if call % 50 == 49:
+            torch.cuda.synchronize()
+            for (wa, _), (wb, _) in zip(envs[0].worlds, envs[1].worlds):
+                for name in _lib.FIELDS:
+                    a, b = wa.view(name), wb.view(name)
+                    assert torch.equal(a, b) or (a.dtype.is_floating_point and bool((a == b).all())), (name, wa.lanes, call)
+    assert envs[0].handover_failures() == 0 and int(envs[0].errors().max()) == 0
+    for e in envs:
+        e.close()
