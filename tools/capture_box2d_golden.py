@@ -82,7 +82,10 @@ def capture_box2d(reference, cases, steps):
                 key = [int(p.id.key) for p in pts] + [0, 0]
                 ni = [float(p.normalImpulse) for p in pts] + [0.0, 0.0]
                 ti = [float(p.tangentImpulse) for p in pts] + [0.0, 0.0]
-                rows.append([int(other.userData["static"]), int(c.touching), int(m.type_), int(m.pointCount), key[0], key[1],
+                mtype = getattr(m, "type_", None)          # (pybox2d names b2Manifold::type `type_`; older SWIG layers `type`)
+                if mtype is None:
+                    mtype = getattr(m, "type")
+                rows.append([int(other.userData["static"]), int(c.touching), int(mtype), int(m.pointCount), key[0], key[1],
                              ni[0], ni[1], ti[0], ti[1]])
             contacts.append(rows)
         return {"bodies": bodies, "joints": js, "contacts": contacts, "wod": env.wod.position}
