@@ -152,3 +152,19 @@ def test_reference_baseline_leg_is_dormant_without_the_wheel(monkeypatch):
     assert "/root/reference" not in src.split("def reference_baseline")[1].split("\ndef ")[0].replace(
         "nothing is\n    read from /root/reference by default", "")
     assert bench.REFERENCE_PYTHON_OVERHEAD["step_us_color_control_on"] == 2287
+
+
+def test_scaling_claim_names_what_the_6x_is_judged_on():
+    """the line of a multi-rank run says which scaling north_star's ">= 6x at 8 GPUs" is judged on (weak: 65 536 per
+    GPU), carries the committed single-GPU line it is compared with and the ratio, and labels a strong-scaling line as such."""
+    import bench
+    ref = bench.n1_reference()
+    assert ref is not None and ref["source"].startswith("profiles/r06_") and 5e7 < ref["value"] < 1e8
+    weak = bench.scaling_claim(8, False, 8 * 65536, 65536, 8 * ref["value"])
+    assert weak["this_line"] == "weak" and weak["creatures_total"] == 524288 and weak["creatures_per_gpu"] == 65536
+    assert abs(weak["vs_n1"] - 8.0) < 1e-9 and "weak scaling" in weak["judged_on"] and ">= 6x" in weak["north_star"]
+    strong = bench.scaling_claim(8, True, 65536, 8192, 1.2 * ref["value"])
+    assert strong["this_line"] == "strong" and "1.2x" in strong["expected"] and abs(strong["vs_n1"] - 1.2) < 1e-9
+    # and the roofline's hardware ceiling is the guide's figure, the measured ones sit beside it
+    assert bench.HW_VALU_ISSUE_PEAK == 1024 * 2.4e9 / 2
+    assert bench.UBENCH_INDEPENDENT["wave_instructions_per_s_at_4_waves_per_simd"] < bench.UBENCH_INDEPENDENT["wave_instructions_per_s_at_8_waves_per_simd"] < bench.HW_VALU_ISSUE_PEAK
