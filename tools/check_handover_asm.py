@@ -14,6 +14,9 @@ back from the code object of a built library:
             a path from the kernel's entry to that invalidate either: the CU's L1 and the scalar cache are dropped before any
             state of the block is read.
 
+Not judged: scalar loads (s_load_*) inside the poll section.  The ones there read the kernel-argument segment (a constant: e.g. the
+failure counter's address), and everything scalar loaded AFTER the section is behind its `s_dcache_inv`.
+
 The graph is read from the disassembly: direct branches, and LLVM's long-branch expansion (s_getpc / s_add / s_addc /
 s_setpc) folded into direct ones; any other computed jump is refused.
 
