@@ -326,7 +326,7 @@ def lib(wide=False):
     return L
 
 
-def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_shape=-1):
+def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_shape=-1, wide=False):
     """Tile plan of the velocity kernel for one morphology batch (rem2d_plan_tiles_shape): int32 tile starts
     [n_tiles + 1].  tile_shape: 0 .. 4, or -1 for the default (3); max_creatures 0: the library's default cap unless
     REM2D_TILE_CREATURES overrides it (experiments)."""
@@ -337,8 +337,9 @@ def plan_tiles(parent, jround, n_envs, lanes, n_padded, max_creatures=0, tile_sh
     n = C.c_int32()
     if max_creatures <= 0:
         max_creatures = env_tile_creatures()
-    check(lib().rem2d_plan_tiles_shape(parent.ctypes.data, jround.ctypes.data, int(n_envs), int(lanes), int(n_padded),
-                                       int(max_creatures), int(tile_shape), out.ctypes.data, C.byref(n)))
+    # (the plan of the build that will run it: the wide build schedules one phase more than the default one, V4_PHASES)
+    check(lib(wide).rem2d_plan_tiles_shape(parent.ctypes.data, jround.ctypes.data, int(n_envs), int(lanes), int(n_padded),
+                                           int(max_creatures), int(tile_shape), out.ctypes.data, C.byref(n)), wide)
     return out[:n.value + 1].copy()
 
 

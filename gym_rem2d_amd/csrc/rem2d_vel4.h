@@ -31,7 +31,22 @@
 //   WPS     waves per SIMD the register allocation targets.
 // More bodies per tile = fewer wavefronts and fuller joint slots; fewer registers = more resident wavefronts to hide
 // the dependent-instruction latency (~10 cycles per instruction for a lone wavefront, measured with s_memtime).
-#define V4_PHASES 5        // largest schedule period the tick loop is unrolled for (reference modules need <= 4; a tile may take one more)
+#ifndef V4_PLUS1_GAIN
+#define V4_PLUS1_GAIN 2    // contact sub-slots per iteration a tile must save to take the period P + 1 (one more joint slot per iteration)
+#endif
+// Largest schedule period the tick loop is unrolled for.  A module of the reference has three connection sites and the joint to its
+// parent (simple_module.py:21-25, circular_module.py:23-27): at most four joints on a body, period <= 4 -- and a tile of period <= 3
+// may still take one more (V4_PLUS1_GAIN).  Round 6: unrolled for 4 instead of 5 the loop is a fifth shorter and needs fewer scalar
+// registers: +1.8 % on config 3, +3.1 % on config 4 (profiles/r06_experiments.txt 11; a period-4 tile loses its option on period 5,
+// which measured as nothing).  The wide build -- the fallback for bodies outside the reference's domain -- keeps 5; a creature
+// beyond a build's V4_PHASES is flagged REM2D_ERR_SOLVER_OVERFLOW like one beyond its contact slots.
+#ifndef V4_PHASES
+#ifdef REM2D_WIDE
+#define V4_PHASES 5
+#else
+#define V4_PHASES 4
+#endif
+#endif
 #define V4_MAX_BODIES 256  // bodies per tile in the widest shape (LDS mailbox size)
 #define V4_MAX_PASSES (V4_MAX_BODIES / WAVE)
 
@@ -409,7 +424,7 @@ DEV void vel4_body(const State &S, const float friction, const Vel4Args &A, unsi
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) { offP[p] = offB[p]; deltaP[p] = delta[p]; }
             const int subsQ = plan(P + 1);
-            if (subsQ + 2 <= subsP) P = P + 1;
+            if (subsQ + V4_PLUS1_GAIN <= subsP) P = P + 1;
             else {
 #pragma unroll
                 for (int p = 0; p < PASSES; ++p) { offB[p] = offP[p]; delta[p] = deltaP[p]; } // (back to the plan for P)

@@ -133,7 +133,7 @@ class BatchedWorld:
             self._check(self.L.rem2d_world_set_tile_shape(self.h, int(tile_shape)))
             self.tile_shape = int(tile_shape)
         self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
-                                     self.n_envs_padded, tile_shape=self.tile_shape)
+                                     self.n_envs_padded, tile_shape=self.tile_shape, wide=self.wide)
         self._check(self.L.rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def adopt(self, morph: Morphology, tile_shape=None):
@@ -148,7 +148,7 @@ class BatchedWorld:
             self._check(self.L.rem2d_world_set_tile_shape(self.h, int(tile_shape)))
             self.tile_shape = int(tile_shape)
         self.tiles = _lib.plan_tiles(morph.arrays["parent"], morph.arrays["jround"], self.n_envs, self.lanes,
-                                     self.n_envs_padded, tile_shape=self.tile_shape)
+                                     self.n_envs_padded, tile_shape=self.tile_shape, wide=self.wide)
         self._check(self.L.rem2d_world_set_tiles(self.h, self.tiles.ctypes.data, len(self.tiles) - 1))
 
     def set_outputs(self, reward, done, index):

@@ -591,3 +591,40 @@ def test_rebalance_by_current_cost_keeps_population_order_results(need_gpu, orac
     uni.reset_morphology(synthetic.chain_population(8192, 4, "left"))
     assert uni._rebalance_steps == 0 and uni.worlds[0][0].get_option("rebalance") == 0
     uni.close()
+
+
+def test_five_joints_on_one_body_fall_back_to_the_wide_build(need_gpu, oracle, flat_terrain):
+    """A module of the reference has three connection sites and the joint to its parent (simple_module.py:21-25,
+    circular_module.py:23-27): at most four joints on a body, schedule period <= 4 -- what the default build unrolls its tick loop
+    for (V4_PHASES, round 6).  A hand-built hub with FIVE children (period 5) is outside that domain: the default build flags it
+    REM2D_ERR_SOLVER_OVERFLOW like a body beyond its contact slots, run_episode re-evaluates it in the wide build (which keeps five
+    phases), and every creature -- the star and the legal period-4 creatures beside it -- gets the oracle's fitness bit for bit."""
+    from gym_rem2d_amd import _lib
+    from gym_rem2d_amd.compiler import CreatureBuilder, CreatureSpec, Morphology
+    from gym_rem2d_amd.env import BatchedModular2D
+    from gym_rem2d_amd.evaluate import run_episode
+
+    def star(n_children):
+        b = CreatureBuilder()
+        hub = b.add_box(0.25, 0.25, 5.0, 7.0, 0.0)
+        for k in range(n_children):
+            ang = 2.0 * np.pi * k / n_children
+            child = b.add_box(0.1, 0.3, 5.0 + 0.55 * np.cos(ang), 7.0 + 0.55 * np.sin(ang), ang - np.pi / 2)
+            b.add_revolute(hub, child, (0.25 * np.cos(ang), 0.25 * np.sin(ang)), (0.0, -0.3), 50.0)
+        return CreatureSpec(b, list(range(n_children + 1)))
+    specs = [star(4), star(5), star(3), star(4)] + [star(4 - k % 2) for k in range(8)]
+    assert [s.period for s in specs[:4]] == [4, 5, 3, 4] and max(s.period for s in specs[4:]) == 4
+    m = Morphology.from_specs(specs, 8)
+    ref = oracle.batch_run(oracle_terrain(oracle, flat_terrain), m.as_dict(), 300, n_threads=4, flags=oracle.FLAG_CONTINUOUS)
+    env = BatchedModular2D(flat=True)
+    env.reset_morphology(m)
+    env.step(5)
+    err = env.errors().cpu().numpy()
+    # (a velocity tile that cannot schedule one of its creatures leaves joints of ANY of them unsolved: the eight creatures of the
+    # star's 64-lane tile carry the flag, the second tile's legal creatures do not)
+    assert err.tolist() == [_lib.ERR_SOLVER_OVERFLOW] * 8 + [0] * 4
+    env.reset_morphology(m)
+    fit = run_episode(env, max_steps=300)
+    assert env.last_overflow == list(range(8)) and env.last_unresolved == []
+    assert np.array_equal(fit.cpu().numpy(), ref["fitness"])
+    env.close()
