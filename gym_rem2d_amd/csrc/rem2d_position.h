@@ -33,9 +33,7 @@ struct PosShared {
 };
 // manifold geometry as the position solver reads it (b2PositionSolverManifold): type | count << 8, local normal,
 // local point, two manifold points
-#ifndef POS_KR
 #define POS_KR 3
-#endif
 struct PosManifold { int tc; V2 ln, lp, p0, p1; };
 DEV void pos_manifold_load(const State &S, unsigned gl, int t, PosManifold &m) {
     const unsigned sb = (unsigned)(t * SCR_WORDS) * S.Lp + gl;
