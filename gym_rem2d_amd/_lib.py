@@ -162,7 +162,9 @@ class HandoverError(Rem2dError):
 # (-instcombine-max-copied-from-constant-users: a kernel reads its by-value `Batch` argument straight from the kernarg segment only
 # while LLVM's scan of the argument's users stays under this limit -- 300 by default, which rem2d_step_train_kernel's inlined
 # phases exceed: the whole 1.5 KB struct was copied to scratch and spilled from there; the other kernels compile the same either way)
-BUILD_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
+# (-Os, round 6: the same arithmetic -- no fast-math, contraction off -- in ~10 % fewer instructions: +1.3 % on configs 3 / 4 and the
+# 8-module chains against -O3; -O2 +0.7 %, -O1 -5 %, -Oz -12 %: profiles/r06_experiments.txt 16)
+BUILD_FLAGS = ["-Os", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
                "-mllvm", "-instcombine-max-copied-from-constant-users=4000"]
 WIDE_FLAGS = ["-DREM2D_WIDE=1"]
 FMA_FLAGS = ["-ffp-contract=fast"]   # (the later -ffp-contract wins over BUILD_FLAGS')

@@ -5,6 +5,6 @@ set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/build/ab
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -mllvm -instcombine-max-copied-from-constant-users=4000 -DREM2D_BUILD_ID="\"variant:$NAME\"" "$@" -I$ROOT/include \
+hipcc -Os --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -shared -mllvm -instcombine-max-copied-from-constant-users=4000 -DREM2D_BUILD_ID="\"variant:$NAME\"" "$@" -I$ROOT/include \
   $ROOT/gym_rem2d_amd/csrc/rem2d.hip -o $ROOT/build/ab/librem2d_$NAME.so
 echo built build/ab/librem2d_$NAME.so
