@@ -77,8 +77,9 @@ class BatchedModular2D:
     BIG_POPULATION = 131072     # creatures per GPU from which the 128-lane tiles of the velocity kernel pay (round 4: 2 joint
                                 # register sets at 4 wavefronts per SIMD, 18.6 active lanes; profiles/r04_sweep_population_shape.txt)
     REBALANCE_EVERY = 50        # env-steps between two re-orderings of a mixed population by current cost (see __init__)
-    TRAIN128_MAX = 163840       # creatures per GPU up to which the 128-lane step train beats per-step launches (profiles/r06_train128.txt:
-                                # 131 072: 71.5 vs 69.6 M env-steps/s; 196 608: 77.6 vs 80.7 M)
+    TRAIN128_MAX = 131072       # creatures per GPU up to which the 128-lane step train is used instead of per-step launches (profiles/
+                                # r06_train128.txt; on the round's final build: 131 072: 71.4 vs 71.3 M env-steps/s, 163 840: 76.1 vs 78.6 M,
+                                # 196 608: 75.5 vs 82.6 M -- the 4-phase loop and -Os helped the per-step launches more)
     TRAIN128_UNIFORM = False    # uniform populations on the static 128-lane shape keep per-step launches on three step groups: 65 536 8-module
                                 # chains 180.7 M against 177.0 M as a train (and 142.5 M as a 64-lane train) -- profiles/r06_train128.txt
 
